@@ -1,0 +1,173 @@
+/*
+ * vad_amd.h - C ABI of libvad_amd.so, the MI355X (gfx950) implementation of the
+ * voice-activity-detection inference hot path:
+ *
+ *     int16 audio frames -> 12 MFCC + 12 delta per 30 ms frame
+ *                        -> 30-frame (900 ms) windows
+ *                        -> GRU / LSTM / DenseNet forward -> 2-class posterior
+ *                        -> thresholded decision
+ *
+ * Conventions
+ *   - Every pointer named *_dev is a DEVICE pointer owned by the caller; every
+ *     pointer named *_host is a host pointer.  Nothing is allocated or freed
+ *     on behalf of the caller except the per-device constant tables created by
+ *     vad_init().
+ *   - Kernels are enqueued on `stream` (a hipStream_t passed as void*, NULL =
+ *     the default stream) and the call returns without synchronising.
+ *   - Return value: 0 on success, a negative VAD_E* code otherwise; no C++
+ *     exception crosses the boundary.  vad_last_error() returns a
+ *     thread-local, human-readable message for the last failure.
+ *   - The reference implementation is pure Python; each entry point cites the
+ *     reference function whose arithmetic it replaces (paths relative to the
+ *     reference repository root).
+ */
+#ifndef VAD_AMD_H
+#define VAD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAD_OK          0
+#define VAD_EINVAL     -1   /* bad argument (null pointer, misalignment, size out of range) */
+#define VAD_EHIP       -2   /* a HIP runtime call failed; see vad_last_error() */
+#define VAD_ENOTINIT   -3   /* vad_init() has not succeeded on the current device */
+
+/* Constants of the path (core/common.py:17-23, core/process_data.py:48-56). */
+#define VAD_SAMPLE_RATE     16000
+#define VAD_FRAME_SIZE      480    /* samples per 30 ms frame */
+#define VAD_ALIGN_FRAMES    3      /* MFCC_WINDOW_FRAME_SIZE - 1 */
+#define VAD_NUM_CEPS        12     /* c1..c12 (c0 dropped, core/process_data.py:276) */
+#define VAD_FEATURES        24     /* 12 MFCC || 12 delta */
+#define VAD_FRAMES          30     /* frames per model window */
+
+/* Decision rule written next to the posterior. */
+#define VAD_DECIDE_ARGMAX     0    /* torch.max(out,1)[1]          core/train.py:605-607 */
+#define VAD_DECIDE_THRESHOLD  1    /* 1 if out[:,1] >= t else 0     core/train.py:486-487 */
+
+/* Version / liveness probe; never touches the GPU. */
+int vad_abi_version(void);
+const char* vad_last_error(void);
+
+/*
+ * Build the constant tables (FFT twiddles, mel segment map, DCT/lifter matrix)
+ * for the CURRENT HIP device.  Idempotent; the compute entry points call it
+ * lazily, but a caller that captures HIP graphs must call it beforehand.
+ */
+int vad_init(void);
+
+/*
+ * MFCC + delta front end.  Replaces, for a batch of slices,
+ *     python_speech_features.mfcc(frames_aligned, 16000, winstep=.03, winlen=.12, nfft=2048)[:, 1:]
+ *     python_speech_features.delta(mfcc, 2)
+ * as called by process_test_frames (core/process_data.py:257-279) and by the
+ * MFCC tail of add_noise (core/process_data.py:299-309).
+ *
+ * frames_dev            int16 samples.  Slice s occupies
+ *                       frames_dev[s*slice_stride .. s*slice_stride + (n_s+3)*480):
+ *                       3 alignment rows followed by its n_s data rows
+ *                       (the concatenation at core/process_data.py:270).
+ *                       slice_stride = frames_per_slice*480 describes one
+ *                       contiguous stream cut into slices (each slice's
+ *                       alignment rows are the previous slice's last rows,
+ *                       core/process_data.py:228-229); (frames_per_slice+3)*480
+ *                       describes independently stored slices.
+ * n_slices              number of slices S >= 1.
+ * frames_per_slice      n_s for all slices but the last.
+ * last_slice_frames     n_s of the last slice, 1..frames_per_slice.
+ * mfcc_dev / mfcc_ld    output row g = s*frames_per_slice + j gets its 12
+ *                       coefficients at mfcc_dev[g*mfcc_ld .. +12).
+ * delta_dev / delta_ld  same for the deltas.  Passing mfcc_ld = delta_ld = 24
+ *                       and delta_dev = mfcc_dev + 12 produces the packed
+ *                       (F,24) feature matrix the models consume
+ *                       (core/generator.py:145-148).
+ *
+ * Per-slice semantics are kept: the first alignment row of a slice is not
+ * pre-emphasised and deltas replicate the slice's own edge rows.
+ * frames_dev must be 4-byte aligned and slice_stride even.
+ */
+int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, int64_t frames_per_slice,
+                       int64_t last_slice_frames, int64_t slice_stride,
+                       float* mfcc_dev, int64_t mfcc_ld, float* delta_dev, int64_t delta_ld,
+                       void* stream);
+
+/*
+ * Weight packing (host side, no GPU work).  State-dict tensors of the
+ * reference module -> one float blob in the layout the kernels read
+ * (MFMA A-operand order, BatchNorm folded).  The caller copies the blob to
+ * the device.
+ *
+ * Net (core/models.py:9-81): rnn.weight_ih_l0 (G*H,24), rnn.weight_hh_l0
+ * (G*H,H), rnn.bias_ih_l0, rnn.bias_hh_l0 (G*H) with G = 3 (GRU: r,z,n) or
+ * 4 (LSTM: i,f,g,o); lin1 (26, 30*H) + (26); lin2 (2,26) + (2); lin (2, 30*H)
+ * + (2).  `large` selects lin1/lin2, otherwise lin; the unused head may be
+ * NULL.  hidden = 30 is the reference architecture; 1..32 is accepted.
+ */
+size_t vad_net_blob_floats(int lstm, int large, int hidden);
+int vad_pack_net_weights(int lstm, int large, int hidden,
+                         const float* w_ih_host, const float* w_hh_host,
+                         const float* b_ih_host, const float* b_hh_host,
+                         const float* lin1_w_host, const float* lin1_b_host,
+                         const float* lin2_w_host, const float* lin2_b_host,
+                         const float* lin_w_host, const float* lin_b_host,
+                         float* blob_host, size_t blob_floats);
+
+/*
+ * DenseNet (core/models.py:383-461).  `tensors_host` lists, in state_dict()
+ * order and skipping every num_batches_tracked entry, the float tensors of
+ * the module: for each Conv1d+BatchNorm1d pair conv.weight, bn.weight,
+ * bn.bias, bn.running_mean, bn.running_var; finally out.weight.
+ * That is 5*(1 + L + 1 + L + 1) + 1 tensors with L = 6 (small) or 8 (large).
+ * BatchNorm uses eps = 1e-5 and is folded into the convolutions.
+ */
+size_t vad_densenet_blob_floats(int large);
+int vad_densenet_tensor_count(int large);
+int vad_pack_densenet_weights(int large, const float* const* tensors_host, int n_tensors,
+                              float* blob_host, size_t blob_floats);
+
+/*
+ * Model forward over windows.  Replaces Net.forward (core/models.py:39-81)
+ * and DenseNet.forward (core/models.py:449-461) in eval mode, plus the
+ * decision step of netvad / far.apply_threshold.
+ *
+ * x_dev           float features.  Window w reads its 30 rows of 24 floats at
+ *                 x_dev[w*window_stride + t*24 .. +24), t = 0..29.
+ *                 window_stride = 720 is a dense (B,30,24) batch as passed to
+ *                 forward(); window_stride = 24 is the stride-1 sliding window
+ *                 over a packed (F,24) feature matrix (core/train.py:566-570),
+ *                 in which case n_windows = F - 29; 24*k gives stride k.
+ *                 Must be 16-byte aligned, window_stride a multiple of 4.
+ * blob_dev        device copy of the packed weights.
+ * p_dev           (n_windows, 2) softmax posteriors; column 1 = speech.
+ * decision_dev    optional (may be NULL) uint8 per window.
+ * decision_mode   VAD_DECIDE_ARGMAX or VAD_DECIDE_THRESHOLD (uses `threshold`).
+ */
+int vad_gru_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                        const float* blob_dev, int hidden, int large,
+                        float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold,
+                        void* stream);
+int vad_lstm_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                         const float* blob_dev, int hidden, int large,
+                         float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold,
+                         void* stream);
+int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                             const float* blob_dev, int large,
+                             float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold,
+                             void* stream);
+
+/*
+ * Deterministic synthetic 16 kHz int16 audio, written on the device: sample n
+ * of stream `seed` is a pure integer function of (seed, n), reproducible on
+ * the host.  No counterpart in the reference (its audio comes from datasets
+ * that do not ship, core/prepare_files.py); used by the benchmark and tests.
+ */
+int vad_synth_audio_i16(int16_t* out_dev, int64_t first_sample, int64_t n_samples,
+                        uint32_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAD_AMD_H */

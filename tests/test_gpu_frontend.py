@@ -1,0 +1,140 @@
+"""GPU parity of the MFCC/delta front end (vad_mfcc_delta_f32) against the CPU oracle.
+
+Tolerance (north star: "MFCC features within 1e-4 relative tolerance"): the
+reference computes in float64, the kernel's FFT in float32, and lifted cepstra
+and especially deltas pass through zero, so the check is
+    |gpu - ref| <= 1e-4 * max(|ref|, FLOOR)      with FLOOR = 1.0
+(lifted cepstra of audible frames span roughly +-60).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mfcc_ref, pipeline_ref, synth_ref
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+FLOOR = 1.0
+
+
+def assert_feat_close(got, ref, what=''):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), FLOOR)
+    worst = np.unravel_index(np.argmax(err), err.shape)
+    assert err.max() <= RTOL, '%s: max scaled err %.3e at %s (got %r ref %r)' % (
+        what, err.max(), worst, got[worst], ref[worst])
+    return err.max()
+
+
+def test_synth_audio_bit_exact(vad):
+    for first, n, seed in [(0, 48000, 1337), (123457, 9999, 7), (2 ** 32 - 1000, 4000, 1337)]:
+        dev = vad.synth_audio(first, n, seed=seed)
+        np.testing.assert_array_equal(dev.cpu().numpy(), synth_ref.synth_audio(first, n, seed))
+
+
+def test_process_test_frames_matches_oracle(vad):
+    fr = synth_ref.synth_frames(50, 169, seed=1337)
+    frames, m, d = vad.process_test_frames(fr[3:], fr[:3])
+    rf, rm, rd = mfcc_ref.process_test_frames(fr[3:], fr[:3])
+    np.testing.assert_array_equal(frames, rf)
+    assert m.shape == (166, 12) and d.shape == (166, 12)
+    assert_feat_close(m, rm, 'mfcc')
+    assert_feat_close(d, rd, 'delta')
+
+
+def test_zero_alignment_and_silence(vad):
+    z = np.zeros((3, 480), np.int16)
+    fr = synth_ref.synth_frames(0, 60, seed=5)
+    _, m, d = vad.process_test_frames(fr, z)
+    _, rm, rd = mfcc_ref.process_test_frames(fr, z)
+    assert_feat_close(m, rm, 'mfcc')
+    assert_feat_close(d, rd, 'delta')
+    # an all-zero slice drives every filter into the zero-energy clamp: cepstra and deltas vanish
+    zz = np.zeros((20, 480), np.int16)
+    _, m0, d0 = vad.process_test_frames(zz, z)
+    assert np.abs(m0).max() < 1e-6 and np.abs(d0).max() < 1e-6
+
+
+def test_full_scale_and_dc(vad):
+    rng = np.random.default_rng(3)
+    fr = rng.integers(-32768, 32768, size=(40, 480)).astype(np.int16)
+    fr[10:14] = 32767                      # saturated DC rows
+    fr[20:22] = -32768
+    al = rng.integers(-32768, 32768, size=(3, 480)).astype(np.int16)
+    _, m, d = vad.process_test_frames(fr, al)
+    _, rm, rd = mfcc_ref.process_test_frames(fr, al)
+    assert_feat_close(m, rm, 'mfcc')
+    assert_feat_close(d, rd, 'delta')
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 5, 33])
+def test_short_slices(vad, n):
+    fr = synth_ref.synth_frames(200, n + 3, seed=11)
+    _, m, d = vad.process_test_frames(fr[3:], fr[:3])
+    _, rm, rd = mfcc_ref.process_test_frames(fr[3:], fr[:3])
+    assert_feat_close(m, rm, 'mfcc')
+    assert_feat_close(d, rd, 'delta')
+
+
+def test_batched_slices(vad):
+    S, N = 7, 50
+    rng = np.random.default_rng(9)
+    slices = np.stack([synth_ref.synth_frames(1000 * s + 17, N + 3, seed=s) for s in range(S)])
+    slices[3] = rng.integers(-500, 500, size=(N + 3, 480))
+    mf, de = vad.mfcc_delta_slices(torch.from_numpy(slices).cuda())
+    for s in range(S):
+        _, rm, rd = mfcc_ref.process_test_frames(slices[s, 3:], slices[s, :3])
+        assert_feat_close(mf[s].cpu().numpy(), rm, 'mfcc slice %d' % s)
+        assert_feat_close(de[s].cpu().numpy(), rd, 'delta slice %d' % s)
+
+
+@pytest.mark.parametrize('n_frames,slice_len', [(400, 166), (332, 166), (167, 166), (100, 0), (500, 33)])
+def test_stream_slicing(vad, n_frames, slice_len):
+    stream = vad.synth_stream(0, n_frames, seed=1337)
+    feat = vad.mfcc_delta_stream(stream, n_frames, slice_len).cpu().numpy()
+    host = synth_ref.synth_frames(0, n_frames, seed=1337)
+    ref = pipeline_ref.features_sliced(host, slice_len)
+    assert_feat_close(feat[:, :12], ref[:, :12], 'mfcc')
+    assert_feat_close(feat[:, 12:], ref[:, 12:], 'delta')
+
+
+def test_stream_starting_mid_stream(vad):
+    """A shard that starts at frame f0 > 0 carries the 3 preceding frames as alignment rows."""
+    f0, n = 166 * 3, 166 * 2
+    stream = vad.synth_stream(f0, n, seed=1337)
+    feat = vad.mfcc_delta_stream(stream, n, 166).cpu().numpy()
+    host = synth_ref.synth_frames(0, f0 + n, seed=1337)
+    ref = pipeline_ref.features_sliced(host, 166)[f0:]
+    assert_feat_close(feat, ref, 'shard')
+
+
+def test_argument_errors(vad):
+    with pytest.raises(ValueError):
+        vad.process_test_frames(np.zeros((4, 481), np.int16), np.zeros((3, 480), np.int16))
+    with pytest.raises(ValueError):
+        vad.process_test_frames(np.zeros((4, 480), np.int16), np.zeros((2, 480), np.int16))
+    with pytest.raises(ValueError):
+        vad.mfcc_delta_stream(torch.zeros(480 * 5, dtype=torch.int16, device='cuda'), 10)
+
+
+def test_large_stream_properties(vad):
+    """Size-independent checks at a size the oracle does not sweep in full (10 min of audio):
+    slices are independent, so any slice recomputed alone must reproduce the big run bit for bit,
+    and spot slices must match the oracle."""
+    n = 166 * 120 + 41
+    stream = vad.synth_stream(0, n, seed=99)
+    feat = vad.mfcc_delta_stream(stream, n, 166)
+    assert torch.isfinite(feat).all()
+    host = stream.cpu().numpy().reshape(-1, 480)
+    for s in (0, 57, 119, 120):
+        lo = 166 * s
+        hi = min(lo + 166, n)
+        aligned = host[lo: hi + 3]
+        mf, de = vad.mfcc_delta_slices(torch.from_numpy(aligned[None]).cuda())
+        assert torch.equal(mf[0], feat[lo:hi, :12]) and torch.equal(de[0], feat[lo:hi, 12:])
+        _, rm, rd = mfcc_ref.process_test_frames(aligned[3:], aligned[:3])
+        assert_feat_close(feat[lo:hi, :12].cpu().numpy(), rm, 'mfcc slice %d' % s)
+        assert_feat_close(feat[lo:hi, 12:].cpu().numpy(), rd, 'delta slice %d' % s)

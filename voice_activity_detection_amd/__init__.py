@@ -1,0 +1,18 @@
+"""MI355X-native VAD inference hot path (MFCC front end + GRU / LSTM / DenseNet window models).
+
+The compute path is libvad_amd.so (HIP, gfx950) behind the C ABI in
+include/vad_amd.h; this package is the Python host side that mirrors the
+reference's entry points.  There is no CPU fallback: without the library and a
+GPU the calls raise ``VadError``.
+"""
+from ._lib import VadError, build, lib
+from .common import (ALIGN_FRAMES, BATCH_SIZE, FEATURES, FRAME_SIZE, FRAMES, SAMPLE_RATE, SLICE_MAX, STEP_SIZE)
+from .models import MODEL_STACK, DenseNet, Net
+from .process_data import (add_noise, mfcc_delta_slices, mfcc_delta_stream, overlay, process_test_frames)
+from .stream import StreamWorkspace, vad_stream
+from .synth import synth_audio, synth_stream
+
+__all__ = ['VadError', 'build', 'lib', 'Net', 'DenseNet', 'MODEL_STACK', 'process_test_frames', 'add_noise',
+           'overlay', 'mfcc_delta_slices', 'mfcc_delta_stream', 'vad_stream', 'StreamWorkspace', 'synth_audio',
+           'synth_stream', 'SAMPLE_RATE', 'FRAME_SIZE', 'FRAMES', 'FEATURES', 'BATCH_SIZE', 'SLICE_MAX',
+           'ALIGN_FRAMES', 'STEP_SIZE']

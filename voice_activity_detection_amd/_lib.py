@@ -1,0 +1,106 @@
+"""ctypes binding of libvad_amd.so (the C ABI declared in include/vad_amd.h).
+
+The library is the only compute path of this package: if it is missing or a
+call fails, a ``VadError`` is raised -- there is no CPU fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvad_amd.so')
+CSRC = os.path.join(_HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
+SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip']
+
+# every symbol include/vad_amd.h declares
+SYMBOLS = [
+    'vad_abi_version', 'vad_last_error', 'vad_init', 'vad_mfcc_delta_f32',
+    'vad_net_blob_floats', 'vad_pack_net_weights',
+    'vad_densenet_blob_floats', 'vad_densenet_tensor_count', 'vad_pack_densenet_weights',
+    'vad_gru_forward_f32', 'vad_lstm_forward_f32', 'vad_densenet_forward_f32',
+    'vad_synth_audio_i16',
+]
+
+
+class VadError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 into the in-tree shared library."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, 'vad_internal.h'), os.path.join(INCLUDE, 'vad_amd.h')]
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-I' + INCLUDE, '-I' + CSRC, '-o', LIB_PATH] + srcs
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises VadError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VadError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                       '(there is no CPU fallback)' % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c_i64, c_f32p, c_void = ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
+    L.vad_abi_version.restype = ctypes.c_int
+    L.vad_last_error.restype = ctypes.c_char_p
+    L.vad_init.restype = ctypes.c_int
+    L.vad_mfcc_delta_f32.restype = ctypes.c_int
+    L.vad_mfcc_delta_f32.argtypes = [c_void, c_i64, c_i64, c_i64, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_void]
+    L.vad_net_blob_floats.restype = ctypes.c_size_t
+    L.vad_net_blob_floats.argtypes = [ctypes.c_int] * 3
+    L.vad_pack_net_weights.restype = ctypes.c_int
+    L.vad_pack_net_weights.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 10 + [ctypes.c_void_p, ctypes.c_size_t]
+    L.vad_densenet_blob_floats.restype = ctypes.c_size_t
+    L.vad_densenet_blob_floats.argtypes = [ctypes.c_int]
+    L.vad_densenet_tensor_count.restype = ctypes.c_int
+    L.vad_densenet_tensor_count.argtypes = [ctypes.c_int]
+    L.vad_pack_densenet_weights.restype = ctypes.c_int
+    L.vad_pack_densenet_weights.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_size_t]
+    fwd = [c_void, c_i64, c_i64, c_void, ctypes.c_int, ctypes.c_int, c_void, c_void, ctypes.c_int,
+           ctypes.c_float, c_void]
+    L.vad_gru_forward_f32.restype = ctypes.c_int
+    L.vad_gru_forward_f32.argtypes = fwd
+    L.vad_lstm_forward_f32.restype = ctypes.c_int
+    L.vad_lstm_forward_f32.argtypes = fwd
+    L.vad_densenet_forward_f32.restype = ctypes.c_int
+    L.vad_densenet_forward_f32.argtypes = [c_void, c_i64, c_i64, c_void, ctypes.c_int, c_void, c_void,
+                                           ctypes.c_int, ctypes.c_float, c_void]
+    L.vad_synth_audio_i16.restype = ctypes.c_int
+    L.vad_synth_audio_i16.argtypes = [c_void, c_i64, c_i64, ctypes.c_uint32, c_void]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise VadError('libvad_amd call failed (%d): %s' % (rc, lib().vad_last_error().decode()))
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_ptr(a):
+    """Pointer to a C-contiguous float32 numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(ctypes.c_void_p)

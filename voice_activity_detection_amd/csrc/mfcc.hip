@@ -1,0 +1,438 @@
+// MFCC + delta front end for gfx950.
+//
+// One 64-lane wave computes one 30 ms frame: it loads the 1920-sample analysis
+// window (4 frames of 480 int16 samples) together with the samples one frame
+// earlier, applies the lag-480 pre-emphasis, runs a 2048-point real FFT as a
+// 1024-point complex FFT held 16 points per lane, converts to a power
+// spectrum, reduces it over the 27 mel segments, takes the log and applies the
+// lifted DCT-II.  The arithmetic follows python_speech_features.mfcc as called
+// at core/process_data.py:272-276 of the reference (rectangular window,
+// nfft 2048, 26 filters, ortho DCT, lifter 22, c0 dropped).
+//
+// FFT decomposition (N = 1024 = 16 x 16 x 4), all index algebra mirrored by
+// tools/fft_lane_model.py:
+//   pass 1  lane n2 holds z[n2 + 64 j]; radix-16 in registers; twiddle W1024^(n2 k1)
+//   xchg 1  through LDS: lane (k1, m2) gathers A[k1][4 m1 + m2]
+//   pass 2  radix-16 in registers; twiddle W64^(m2 q1)
+//   pass 3  radix-4 across the 4 lanes of a quad with DPP quad_perm moves;
+//           lane r of a quad ends with q2 = bitrev2(r)
+//   result  lane (k1, r), register q1 holds Z[k1 + 16 q1 + 256 q2]
+// The real-input untangle needs Z[k] and Z[1024 - k], so Z takes one more trip
+// through LDS; the power spectrum is left in LDS for the mel stage.
+//
+// Precision: FFT, power and mel sums in fp32; filter energies, log and DCT in
+// fp64 (26 logs and 312 fused multiply-adds per frame), because an fp32 log of
+// an energy near e^25 already carries 2e-6 absolute error before the DCT.
+
+#include <math.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+#include "vad_internal.h"
+
+namespace vad {
+
+namespace {
+
+constexpr int kFrame = VAD_FRAME_SIZE;        // 480
+constexpr int kNFilt = 26;
+constexpr int kNCep = VAD_NUM_CEPS;           // 12
+constexpr int kWavesPerBlock = 4;
+constexpr int kFramesPerWave = 4;
+constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
+constexpr int kMaxRun = 20;                   // bins per lane in the mel stage
+constexpr int kExStride = 68;                 // complex elements per k1 row of exchange 1
+
+struct MfccTables {
+    float2 tw1[15][64];      // [k1-1][lane]   W1024^(lane * k1)
+    float2 tw2[15][4];       // [q1-1][m2]     W64^(m2 * q1)
+    float2 twr[16][64];      // [j][lane]      W2048^(lane + 64 j)
+    int run_start[64];       // mel stage: first bin of the lane's run
+    int run_count[64];       //            bins in the run (0 for idle lanes)
+    int run_b0[64];          //            first bin of the run's segment
+    int run_b1[64];          //            one past the last bin of the segment
+    float run_inv[64];       //            1 / (b1 - b0)
+    int rise_first[kNFilt];  // filter f = rising parts of lanes [rise_first, +rise_n)
+    int rise_n[kNFilt];
+    int fall_first[kNFilt];  //          + falling parts of lanes [fall_first, +fall_n)
+    int fall_n[kNFilt];
+    double dct[kNFilt][kNCep];   // sqrt(2/26) * lifter(k) * cos(pi k (2n+1) / 52), k = 1..12
+};
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// Forward 4-point DFT in place (W4 = -i).
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3);
+    const float2 d = csub(a1, a3);
+    const float2 t3 = make_float2(d.y, -d.x);          // (a1 - a3) * (-i)
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+
+// Forward 16-point DFT in place, natural order in and out.
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128673848f;      // cos(pi/8)
+    constexpr float S1 = 0.38268343236508978178f;      // sin(pi/8)
+    constexpr float R2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // v[4c + b] *= W16^(b c)
+    v[5] = cmul(v[5], make_float2(C1, -S1));           // b=1 c=1
+    v[9] = cmul(v[9], make_float2(R2, -R2));           // b=1 c=2
+    v[13] = cmul(v[13], make_float2(S1, -C1));         // b=1 c=3
+    v[6] = cmul(v[6], make_float2(R2, -R2));           // b=2 c=1
+    v[10] = make_float2(v[10].y, -v[10].x);            // b=2 c=2  (-i)
+    v[14] = cmul(v[14], make_float2(-R2, -R2));        // b=2 c=3
+    v[7] = cmul(v[7], make_float2(S1, -C1));           // b=3 c=1
+    v[11] = cmul(v[11], make_float2(-R2, -R2));        // b=3 c=2
+    v[15] = cmul(v[15], make_float2(-C1, S1));         // b=3 c=3  W16^9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    // X[c + 4 d] sits at v[4 c + d]: transpose the 4x4 register block.
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = c + 1; d < 4; ++d) {
+            const float2 t = v[4 * c + d];
+            v[4 * c + d] = v[4 * d + c];
+            v[4 * d + c] = t;
+        }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+
+// LDS traffic below is between lanes of ONE wave.  LDS operations of a wave
+// complete in issue order, so only the compiler has to be kept from moving
+// loads above the stores of other lanes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kWaveLdsBytes = 16 * kExStride * 8 /*exchange / Z*/ + 1024 * 4 /*power*/ + 2 * 64 * 4 /*partials*/ +
+                              32 * 8 /*log energies*/;
+
+__global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict__ in, const MfccTables* __restrict__ tab,
+                                                      long n_frames, long frames_per_slice, long slice_stride,
+                                                      float* __restrict__ out, long out_ld) {
+    __shared__ __align__(16) unsigned char smem[kWavesPerBlock * kWaveLdsBytes + kNFilt * kNCep * 8];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    unsigned char* wbase = smem + wave * kWaveLdsBytes;
+    float2* ex = reinterpret_cast<float2*>(wbase);                          // 16 x 68 complex
+    float* pw = reinterpret_cast<float*>(wbase + 16 * kExStride * 8);        // 1024 floats
+    float* part_r = pw + 1024;
+    float* part_f = part_r + 64;
+    double* logv = reinterpret_cast<double*>(part_f + 64);
+    double* dct_s = reinterpret_cast<double*>(smem + kWavesPerBlock * kWaveLdsBytes);
+
+    for (int i = threadIdx.x; i < kNFilt * kNCep; i += blockDim.x) dct_s[i] = (&tab->dct[0][0])[i];
+    __syncthreads();
+
+    // Loop-invariant per-lane constants.
+    float2 tw1[15], tw2[15], twr[16];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) tw1[k] = tab->tw1[k][lane];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) tw2[k] = tab->tw2[k][lane & 3];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) twr[j] = tab->twr[j][lane];
+    const int run_start = tab->run_start[lane];
+    const int run_count = tab->run_count[lane];
+    const float run_b0 = (float)tab->run_b0[lane];
+    const float run_b1 = (float)tab->run_b1[lane];
+    const float run_inv = tab->run_inv[lane];
+
+    const int r4 = lane & 3;
+    const float sA = (r4 & 2) ? -1.0f : 1.0f;
+    const float cx = (r4 & 1) ? -1.0f : 1.0f;              // r: 0 -> +, 1 -> -, 2 -> +, 3 -> -
+    const float cy = (r4 == 0 || r4 == 3) ? 1.0f : -1.0f;  // r: 0 -> +, 1 -> -, 2 -> -, 3 -> +
+    const bool is2 = (r4 == 2);
+    const bool swp = (r4 >= 2);
+    const int q2 = ((r4 & 1) << 1) | (r4 >> 1);
+
+    const long first = (long)blockIdx.x * kFramesPerBlock + wave;
+    for (int it = 0; it < kFramesPerWave; ++it) {
+        const long g = first + (long)it * kWavesPerBlock;
+        if (g >= n_frames) break;                           // wave-uniform
+        const long s = g / frames_per_slice;
+        const long j = g - s * frames_per_slice;
+        const int* src = reinterpret_cast<const int*>(in + s * slice_stride + j * kFrame);
+
+        // ---- load + pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj ----
+        float2 v[16];
+#pragma unroll
+        for (int jj = 0; jj < 15; ++jj) {
+            const int n = lane + 64 * jj;
+            const int cur = src[n];
+            float x0 = (float)(short)(cur & 0xFFFF);
+            float x1 = (float)(cur >> 16);
+            // Sample 2n lies in aligned row 2n/480; row 0 of a slice has no predecessor.
+            if (j > 0 || n >= kFrame / 2) {
+                const int prv = src[n - kFrame / 2];
+                x0 = fmaf(-0.97f, (float)(short)(prv & 0xFFFF), x0);
+                x1 = fmaf(-0.97f, (float)(prv >> 16), x1);
+            }
+            v[jj] = make_float2(x0, x1);
+        }
+        v[15] = make_float2(0.0f, 0.0f);                    // samples 1920..2047 are zero padding
+
+        // ---- pass 1 ----
+        dft16(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw1[k - 1]);
+
+        // ---- exchange 1: [k1][n2] -> lane (k1, m2) reads n2 = 4 m1 + m2 ----
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ex[k * kExStride + lane] = v[k];
+        wave_lds_fence();
+        {
+            const float2* rd = ex + (lane >> 2) * kExStride + (lane & 3);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m] = rd[4 * m];
+        }
+        wave_lds_fence();
+
+        // ---- pass 2 ----
+        dft16(v);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw2[k - 1]);
+
+        // ---- pass 3: radix-4 across the quad ----
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float2 p = make_float2(dpp_quad<0x4E>(v[k].x), dpp_quad<0x4E>(v[k].y));      // lane ^ 2
+            const float2 t = make_float2(fmaf(sA, v[k].x, p.x), fmaf(sA, v[k].y, p.y));
+            p = make_float2(dpp_quad<0xB1>(t.x), dpp_quad<0xB1>(t.y));                    // lane ^ 1
+            const float2 u = is2 ? t : p;
+            const float2 w = is2 ? p : t;
+            const float wx = swp ? w.y : w.x;
+            const float wy = swp ? w.x : w.y;
+            v[k] = make_float2(fmaf(cx, wx, u.x), fmaf(cy, wy, u.y));
+        }
+
+        // ---- Z[k] to LDS at k + 4 (k >> 8), k = k1 + 16 q1 + 256 q2 ----
+        {
+            float2* wr = ex + (lane >> 2) + 260 * q2;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) wr[16 * k] = v[k];
+        }
+        wave_lds_fence();
+
+        // ---- real-input untangle and power spectrum for bins k = lane + 64 jj ----
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int k = lane + 64 * jj;
+            const int kk = (1024 - k) & 1023;
+            const float2 a = ex[k + 4 * (jj >> 2)];
+            const float2 b = ex[kk + 4 * (kk >> 8)];
+            const float2 e = make_float2(a.x + b.x, a.y - b.y);          // Z[k] + conj(Z[N-k])
+            const float2 o = make_float2(a.x - b.x, a.y + b.y);          // Z[k] - conj(Z[N-k])
+            const float2 wo = cmul(twr[jj], o);
+            const float xr = e.x + wo.y;                                  // 2 Re X[k]
+            const float xi = e.y - wo.x;                                  // 2 Im X[k]
+            pw[k] = (xr * xr + xi * xi) * (0.25f / 2048.0f);
+        }
+        wave_lds_fence();
+
+        // ---- mel segments: each lane sums a run of <= 20 bins of one segment ----
+        {
+            float sr = 0.0f, sf = 0.0f;
+#pragma unroll 4
+            for (int i = 0; i < kMaxRun; ++i) {
+                if (i < run_count) {
+                    const int bin = run_start + i;
+                    const float p = pw[bin];
+                    const float fb = (float)bin;
+                    sr = fmaf(p, (fb - run_b0) * run_inv, sr);
+                    sf = fmaf(p, (run_b1 - fb) * run_inv, sf);
+                }
+            }
+            part_r[lane] = sr;
+            part_f[lane] = sf;
+        }
+        wave_lds_fence();
+
+        if (lane < kNFilt) {
+            double e = 0.0;
+            const int rf = tab->rise_first[lane], rn = tab->rise_n[lane];
+            const int ff = tab->fall_first[lane], fn = tab->fall_n[lane];
+            for (int i = 0; i < rn; ++i) e += (double)part_r[rf + i];
+            for (int i = 0; i < fn; ++i) e += (double)part_f[ff + i];
+            if (e == 0.0) e = 2.220446049250313e-16;        // psf.fbank zero-energy clamp
+            logv[lane] = log(e);
+        }
+        wave_lds_fence();
+
+        if (lane < kNCep) {
+            double c = 0.0;
+#pragma unroll
+            for (int n = 0; n < kNFilt; ++n) c = fma(logv[n], dct_s[n * kNCep + lane], c);
+            out[g * out_ld + lane] = (float)c;
+        }
+        wave_lds_fence();
+    }
+}
+
+// delta[g] = (-2 f[g-2] - f[g-1] + f[g+1] + 2 f[g+2]) / 10 with the slice's own edge rows
+// replicated (python_speech_features.delta(feat, 2), core/process_data.py:277).
+__global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ mfcc, long mfcc_ld, long n_frames,
+                                                    long frames_per_slice, float* __restrict__ delta, long delta_ld) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_frames * kNCep) return;
+    const long g = idx / kNCep;
+    const int c = (int)(idx - g * kNCep);
+    const long s = g / frames_per_slice;
+    const long lo = s * frames_per_slice;
+    long hi = lo + frames_per_slice - 1;
+    if (hi > n_frames - 1) hi = n_frames - 1;
+    auto at = [&](long r) {
+        r = r < lo ? lo : (r > hi ? hi : r);
+        return mfcc[r * mfcc_ld + c];
+    };
+    const float d = (2.0f * (at(g + 2) - at(g - 2)) + (at(g + 1) - at(g - 1))) / 10.0f;
+    delta[g * delta_ld + c] = d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: tables
+
+double hz2mel(double hz) { return 2595.0 * log10(1.0 + hz / 700.0); }
+double mel2hz(double mel) { return 700.0 * (pow(10.0, mel / 2595.0) - 1.0); }
+
+void build_tables(MfccTables& t) {
+    memset(&t, 0, sizeof(t));
+    const double pi = 3.14159265358979323846;
+    for (int k1 = 1; k1 < 16; ++k1)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * pi * (double)(l * k1) / 1024.0;
+            t.tw1[k1 - 1][l] = make_float2((float)cos(a), (float)sin(a));
+        }
+    for (int q1 = 1; q1 < 16; ++q1)
+        for (int m2 = 0; m2 < 4; ++m2) {
+            const double a = -2.0 * pi * (double)(m2 * q1) / 64.0;
+            t.tw2[q1 - 1][m2] = make_float2((float)cos(a), (float)sin(a));
+        }
+    for (int j = 0; j < 16; ++j)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * pi * (double)(l + 64 * j) / 2048.0;
+            t.twr[j][l] = make_float2((float)cos(a), (float)sin(a));
+        }
+
+    // 28 bin edges of the 26 triangular filters: floor((nfft + 1) * hz / fs) on a mel-linear grid.
+    int edge[kNFilt + 2];
+    const double lowmel = hz2mel(0.0), highmel = hz2mel(VAD_SAMPLE_RATE / 2.0);
+    for (int i = 0; i < kNFilt + 2; ++i) {
+        const double mel = lowmel + (highmel - lowmel) * (double)i / (double)(kNFilt + 1);
+        edge[i] = (int)floor((2048 + 1) * mel2hz(mel) / VAD_SAMPLE_RATE);
+    }
+    // Segment s = bins [edge[s], edge[s+1]) feeds the rising edge of filter s and the falling
+    // edge of filter s-1.  Lanes are dealt to segments so that no lane sums more than kMaxRun bins.
+    int seg_first[kNFilt + 1], seg_n[kNFilt + 1];
+    int lane = 0;
+    for (int s = 0; s <= kNFilt; ++s) {
+        const int len = edge[s + 1] - edge[s];
+        const int nl = (len + kMaxRun - 1) / kMaxRun;
+        const int chunk = (len + nl - 1) / nl;
+        seg_first[s] = lane;
+        seg_n[s] = nl;
+        for (int i = 0; i < nl; ++i, ++lane) {
+            if (lane >= 64) abort();
+            const int st = edge[s] + i * chunk;
+            int cnt = edge[s + 1] - st;
+            if (cnt > chunk) cnt = chunk;
+            if (cnt < 0) cnt = 0;
+            t.run_start[lane] = st;
+            t.run_count[lane] = cnt;
+            t.run_b0[lane] = edge[s];
+            t.run_b1[lane] = edge[s + 1];
+            t.run_inv[lane] = (float)(1.0 / (double)len);
+        }
+    }
+    for (int f = 0; f < kNFilt; ++f) {
+        t.rise_first[f] = seg_first[f];
+        t.rise_n[f] = seg_n[f];
+        t.fall_first[f] = seg_first[f + 1];
+        t.fall_n[f] = seg_n[f + 1];
+    }
+    for (int n = 0; n < kNFilt; ++n)
+        for (int k = 1; k <= kNCep; ++k) {
+            const double lift = 1.0 + 11.0 * sin(pi * (double)k / 22.0);
+            t.dct[n][k - 1] = sqrt(2.0 / kNFilt) * lift * cos(pi * (double)k * (2.0 * n + 1.0) / (2.0 * kNFilt));
+        }
+}
+
+constexpr int kMaxDevices = 64;
+std::mutex g_mu;
+MfccTables* g_tables[kMaxDevices] = {nullptr};
+
+}  // namespace
+
+int ensure_mfcc_tables() {
+    int dev = 0;
+    VAD_HIP_CHECK(hipGetDevice(&dev));
+    VAD_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_tables[dev]) return VAD_OK;
+    static MfccTables host;            // built once, copied per device
+    static bool built = false;
+    if (!built) {
+        build_tables(host);
+        built = true;
+    }
+    MfccTables* d = nullptr;
+    VAD_HIP_CHECK(hipMalloc(&d, sizeof(MfccTables)));
+    VAD_HIP_CHECK(hipMemcpy(d, &host, sizeof(MfccTables), hipMemcpyHostToDevice));
+    g_tables[dev] = d;
+    return VAD_OK;
+}
+
+}  // namespace vad
+
+extern "C" int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, int64_t frames_per_slice,
+                                  int64_t last_slice_frames, int64_t slice_stride, float* mfcc_dev, int64_t mfcc_ld,
+                                  float* delta_dev, int64_t delta_ld, void* stream) {
+    using namespace vad;
+    VAD_REQUIRE(frames_dev && mfcc_dev && delta_dev, "null pointer argument");
+    VAD_REQUIRE(n_slices >= 1 && frames_per_slice >= 1, "n_slices and frames_per_slice must be >= 1");
+    VAD_REQUIRE(last_slice_frames >= 1 && last_slice_frames <= frames_per_slice,
+                "last_slice_frames must be in 1..frames_per_slice");
+    VAD_REQUIRE(mfcc_ld >= kNCep && delta_ld >= kNCep, "leading dimensions must be >= 12");
+    VAD_REQUIRE(slice_stride >= 0 && (slice_stride % 2) == 0, "slice_stride must be even and non-negative");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(frames_dev) & 3) == 0, "frames_dev must be 4-byte aligned");
+    VAD_REQUIRE(n_slices < (int64_t(1) << 40) && frames_per_slice < (int64_t(1) << 40), "size out of range");
+    int rc = ensure_mfcc_tables();
+    if (rc != VAD_OK) return rc;
+    int dev = 0;
+    VAD_HIP_CHECK(hipGetDevice(&dev));
+    const long n_frames = (long)((n_slices - 1) * frames_per_slice + last_slice_frames);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const long blocks = (n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
+    VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many frames for one launch");
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(256), 0, st, frames_dev, g_tables[dev], n_frames,
+                       (long)frames_per_slice, (long)slice_stride, mfcc_dev, (long)mfcc_ld);
+    VAD_HIP_CHECK(hipGetLastError());
+    const long dthreads = n_frames * kNCep;
+    const long dblocks = (dthreads + 255) / 256;
+    VAD_REQUIRE(dblocks <= 0x7FFFFFFFL, "too many frames for one launch");
+    hipLaunchKernelGGL(delta_kernel, dim3((unsigned)dblocks), dim3(256), 0, st, mfcc_dev, (long)mfcc_ld, n_frames,
+                       (long)frames_per_slice, delta_dev, (long)delta_ld);
+    VAD_HIP_CHECK(hipGetLastError());
+    return VAD_OK;
+}

@@ -1,0 +1,349 @@
+// GRU / LSTM window classifier for gfx950: Net.forward of the reference
+// (core/models.py:39-81) over many 30 x 24 windows at once.
+//
+// Mapping.  One wave owns a tile of 32 windows.  Every matrix product of the
+// cell is computed transposed on the fp32 matrix cores,
+//
+//     G^T (gate-unit x window)  =  W (gate-unit x k)  .  V^T (k x window)
+//
+// with v_mfma_f32_32x32x2_f32: the weight matrix is the A operand (one
+// 32-row tile per gate), the window data (input features or hidden state) is
+// the B operand, and the 32 x 32 result has the window on the lane and the
+// gate units in the 16 accumulator registers.  The result layout is the
+// reason for the transposition: register i of lane half hh holds unit
+// u(i, hh) = (i & 3) + 8 (i >> 2) + 4 hh, which is exactly the B-operand
+// shape of the next step (k-step i takes k = 2 i + hh from lane half hh) once
+// the weight columns are stored in the order u(i, hh).  The hidden state
+// therefore never leaves its registers: no LDS round trip, no cross-lane
+// traffic in the recurrence.  The r/z/n (or i/f/g/o) pre-activations of one
+// unit land in the same lane and register index of their tiles, so the gate
+// non-linearities are plain per-lane VALU work that overlaps the MFMAs of the
+// other wave on the SIMD.
+//
+// The first Linear layer (900 -> 26) is accumulated step by step as one more
+// 32-row tile,  L^T += W1[:, 30 t + u] . h_t^T , so the (B, 30, 30) tensor of
+// hidden states is never materialised.  fp32 MFMA is a k-ordered fmaf chain:
+// results are exact fp32, no reduced-precision operand anywhere.
+
+#include <math.h>
+#include <string.h>
+
+#include "vad_internal.h"
+
+namespace vad {
+
+namespace {
+
+constexpr int kT = VAD_FRAMES;      // 30 steps
+constexpr int kF = VAD_FEATURES;    // 24 features
+constexpr int kKs = kF / 2;         // 12 k-steps of the input projection
+constexpr int kHp = 32;             // padded hidden size (one 32-row tile per gate)
+constexpr int kHk = kHp / 2;        // 16 k-steps of the recurrent product
+constexpr int kL1 = 26;             // lin1 outputs
+constexpr int kWindowsPerWave = 32;
+constexpr int kWavesPerBlock = 4;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Blob layout in floats; shared by the host packer and the kernel.
+struct NetLayout {
+    int gates;        // 3 GRU, 4 LSTM
+    int a_ih;         // [gates][12][64]   A operands of the input projection
+    int a_hh;         // [gates][16][64]   A operands of the recurrent product
+    int cb;           // [4][2][16]        accumulator initial values (biases), per lane half
+    int lds_floats;   // everything above is staged in LDS
+    int head;         // large: a1 [30][16][64], b1e [2][16], w2e [2][2][16], b2 [4]
+                      // small: wl [30][2][2][16] (class, half, reg), bl [4]
+    int total;
+};
+
+__host__ __device__ inline NetLayout net_layout(bool lstm, bool large) {
+    NetLayout L;
+    L.gates = lstm ? 4 : 3;
+    L.a_ih = 0;
+    L.a_hh = L.a_ih + L.gates * kKs * 64;
+    L.cb = L.a_hh + L.gates * kHk * 64;
+    L.lds_floats = L.cb + 4 * 2 * 16;
+    L.head = L.lds_floats;
+    L.total = L.head + (large ? (kT * kHk * 64 + 2 * 16 + 2 * 2 * 16 + 4) : (kT * 2 * 2 * 16 + 4));
+    return L;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <bool LSTM, bool LARGE>
+__global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x, long n_windows, long wstride,
+                                                     const float* __restrict__ blob, float* __restrict__ p_out,
+                                                     uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    constexpr int G = LSTM ? 4 : 3;
+    extern __shared__ __align__(16) float lds[];
+    const NetLayout L = net_layout(LSTM, LARGE);
+    const int small_head_floats = LARGE ? 0 : kT * 2 * 2 * 16;
+    for (int i = threadIdx.x; i < L.lds_floats + small_head_floats; i += blockDim.x) lds[i] = blob[i];
+    __syncthreads();
+    const float* a_ih = lds + L.a_ih;
+    const float* a_hh = lds + L.a_hh;
+    const float* cb = lds + L.cb;
+    const float* wl = lds + L.head;                 // small head only
+    const float* a1 = blob + L.head;                // large head only (stays in L2)
+
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const long tile = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long w = tile * kWindowsPerWave + col;
+    if (tile * kWindowsPerWave >= n_windows) return;            // wave-uniform
+    const long wc = w < n_windows ? w : n_windows - 1;          // clamp loads, mask the store
+    const float* xw = x + wc * wstride + 12 * half;
+
+    f32x16 h, c, lacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { h[i] = 0.0f; c[i] = 0.0f; lacc[i] = 0.0f; }
+    float l0 = 0.0f, l1 = 0.0f;
+
+    float4 xa = *reinterpret_cast<const float4*>(xw);
+    float4 xb = *reinterpret_cast<const float4*>(xw + 4);
+    float4 xc = *reinterpret_cast<const float4*>(xw + 8);
+
+    for (int t = 0; t < kT; ++t) {
+        const float xv[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+        {   // prefetch the next step's features
+            const int tn = t + 1 < kT ? t + 1 : t;
+            xa = *reinterpret_cast<const float4*>(xw + tn * kF);
+            xb = *reinterpret_cast<const float4*>(xw + tn * kF + 4);
+            xc = *reinterpret_cast<const float4*>(xw + tn * kF + 8);
+        }
+        float a1v[16];
+        if (LARGE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
+        }
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4* src = reinterpret_cast<const float4*>(cb + (a * 2 + half) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = src[q];
+                acc[a][4 * q] = v.x; acc[a][4 * q + 1] = v.y; acc[a][4 * q + 2] = v.z; acc[a][4 * q + 3] = v.w;
+            }
+        }
+
+        // input projection, K = 24: k-step s takes feature s from lane half 0 and s + 12 from half 1
+#pragma unroll
+        for (int s = 0; s < kKs; ++s) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = MFMA(a_ih[(g * kKs + s) * 64 + lane], xv[s], acc[g]);
+        }
+        // recurrent product, K = 32: k-step i takes unit u(i, half) = the lane's own h[i]
+        if (t > 0) {
+#pragma unroll
+            for (int i = 0; i < kHk; ++i) {
+                const float hv = h[i];
+                if (LSTM) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = MFMA(a_hh[(g * kHk + i) * 64 + lane], hv, acc[g]);
+                } else {
+                    acc[0] = MFMA(a_hh[(0 * kHk + i) * 64 + lane], hv, acc[0]);
+                    acc[1] = MFMA(a_hh[(1 * kHk + i) * 64 + lane], hv, acc[1]);
+                    acc[3] = MFMA(a_hh[(2 * kHk + i) * 64 + lane], hv, acc[3]);   // W_hn h + b_hn kept apart
+                }
+            }
+        }
+
+        // gate non-linearities, elementwise in (unit, window)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (LSTM) {
+                const float ig = fast_sigmoid(acc[0][i]);
+                const float fg = fast_sigmoid(acc[1][i]);
+                const float gg = fast_tanh(acc[2][i]);
+                const float og = fast_sigmoid(acc[3][i]);
+                const float cn = fmaf(fg, c[i], ig * gg);
+                c[i] = cn;
+                h[i] = og * fast_tanh(cn);
+            } else {
+                const float r = fast_sigmoid(acc[0][i]);
+                const float z = fast_sigmoid(acc[1][i]);
+                const float n = fast_tanh(fmaf(r, acc[3][i], acc[2][i]));
+                h[i] = fmaf(z, h[i] - n, n);
+            }
+        }
+
+        // head: flatten index is t * H + unit
+        if (LARGE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lacc = MFMA(a1v[i], h[i], lacc);
+        } else {
+            const float* w0 = wl + ((t * 2 + 0) * 2 + half) * 16;
+            const float* w1 = wl + ((t * 2 + 1) * 2 + half) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                l0 = fmaf(h[i], w0[i], l0);
+                l1 = fmaf(h[i], w1[i], l1);
+            }
+        }
+    }
+
+    // epilogue: (ReLU, lin2) or the tail of lin; softmax over the 2 classes; decision
+    const float* tail = blob + L.head + (LARGE ? kT * kHk * 64 : kT * 2 * 2 * 16);
+    if (LARGE) {
+        const float* b1e = tail + half * 16;
+        const float* w2a = tail + 32 + (0 * 2 + half) * 16;
+        const float* w2b = tail + 32 + (1 * 2 + half) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = fmaxf(lacc[i] + b1e[i], 0.0f);
+            l0 = fmaf(v, w2a[i], l0);
+            l1 = fmaf(v, w2b[i], l1);
+        }
+        tail += 32 + 64;
+    }
+    l0 += __shfl_xor(l0, 32, 64);
+    l1 += __shfl_xor(l1, 32, 64);
+    l0 += tail[0];
+    l1 += tail[1];
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float inv = 1.0f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    if (half == 0 && w < n_windows) {
+        *reinterpret_cast<float2*>(p_out + 2 * w) = make_float2(p0, p1);
+        if (dec_out) dec_out[w] = (mode == VAD_DECIDE_THRESHOLD) ? (p1 >= threshold) : (p1 > p0);
+    }
+}
+
+template <bool LSTM, bool LARGE>
+int launch(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
+           float threshold, hipStream_t st) {
+    const NetLayout L = net_layout(LSTM, LARGE);
+    const size_t lds_bytes = (size_t)(L.lds_floats + (LARGE ? 0 : kT * 2 * 2 * 16)) * sizeof(float);
+    const long per_block = (long)kWindowsPerWave * kWavesPerBlock;
+    const long blocks = (n_windows + per_block - 1) / per_block;
+    VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
+    hipLaunchKernelGGL((rnn_kernel<LSTM, LARGE>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds_bytes, st, x,
+                       n_windows, wstride, blob, p, dec, mode, threshold);
+    VAD_HIP_CHECK(hipGetLastError());
+    return VAD_OK;
+}
+
+int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const float* blob, int hidden, int large,
+            float* p, uint8_t* dec, int mode, float threshold, void* stream) {
+    VAD_REQUIRE(x && blob && p, "null pointer argument");
+    VAD_REQUIRE(hidden >= 1 && hidden <= kHp, "hidden must be in 1..32 (got %d)", hidden);
+    VAD_REQUIRE(n_windows >= 0, "n_windows must be >= 0");
+    VAD_REQUIRE(wstride >= 0 && (wstride % 4) == 0, "window_stride must be a non-negative multiple of 4 floats");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x_dev must be 16-byte aligned");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(p) & 7) == 0, "p_dev must be 8-byte aligned");
+    VAD_REQUIRE(mode == VAD_DECIDE_ARGMAX || mode == VAD_DECIDE_THRESHOLD, "unknown decision_mode %d", mode);
+    if (n_windows == 0) return VAD_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (lstm) {
+        return large ? launch<true, true>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
+                     : launch<true, false>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
+    }
+    return large ? launch<false, true>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
+                 : launch<false, false>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
+}
+
+}  // namespace
+
+}  // namespace vad
+
+extern "C" size_t vad_net_blob_floats(int lstm, int large, int hidden) {
+    (void)hidden;
+    return (size_t)vad::net_layout(lstm != 0, large != 0).total;
+}
+
+extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float* w_ih, const float* w_hh,
+                                    const float* b_ih, const float* b_hh, const float* lin1_w, const float* lin1_b,
+                                    const float* lin2_w, const float* lin2_b, const float* lin_w, const float* lin_b,
+                                    float* blob, size_t blob_floats) {
+    using namespace vad;
+    VAD_REQUIRE(w_ih && w_hh && b_ih && b_hh && blob, "null pointer argument");
+    VAD_REQUIRE(hidden >= 1 && hidden <= kHp, "hidden must be in 1..32 (got %d)", hidden);
+    if (large) VAD_REQUIRE(lin1_w && lin1_b && lin2_w && lin2_b, "large head needs lin1 and lin2");
+    else VAD_REQUIRE(lin_w && lin_b, "small head needs lin");
+    const NetLayout L = net_layout(lstm != 0, large != 0);
+    VAD_REQUIRE(blob_floats >= (size_t)L.total, "blob too small: need %d floats", L.total);
+    const int H = hidden, G = L.gates;
+    memset(blob, 0, sizeof(float) * (size_t)L.total);
+    for (int g = 0; g < G; ++g)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 31, hh = lane >> 5;
+            if (m >= H) continue;
+            for (int s = 0; s < kKs; ++s) blob[L.a_ih + (g * kKs + s) * 64 + lane] = w_ih[(g * H + m) * kF + s + 12 * hh];
+            for (int i = 0; i < kHk; ++i) {
+                const int u = mfma32_row(i, hh);
+                if (u < H) blob[L.a_hh + (g * kHk + i) * 64 + lane] = w_hh[(g * H + m) * H + u];
+            }
+        }
+    for (int hh = 0; hh < 2; ++hh)
+        for (int i = 0; i < 16; ++i) {
+            const int u = mfma32_row(i, hh);
+            if (u >= H) continue;
+            float* cb = blob + L.cb;
+            if (lstm) {
+                for (int g = 0; g < 4; ++g) cb[(g * 2 + hh) * 16 + i] = b_ih[g * H + u] + b_hh[g * H + u];
+            } else {
+                cb[(0 * 2 + hh) * 16 + i] = b_ih[u] + b_hh[u];                    // r
+                cb[(1 * 2 + hh) * 16 + i] = b_ih[H + u] + b_hh[H + u];            // z
+                cb[(2 * 2 + hh) * 16 + i] = b_ih[2 * H + u];                      // W_in x + b_in
+                cb[(3 * 2 + hh) * 16 + i] = b_hh[2 * H + u];                      // W_hn h + b_hn
+            }
+        }
+    float* head = blob + L.head;
+    if (large) {
+        for (int t = 0; t < kT; ++t)
+            for (int i = 0; i < kHk; ++i)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int o = lane & 31, u = mfma32_row(i, lane >> 5);
+                    if (o < kL1 && u < H) head[(t * kHk + i) * 64 + lane] = lin1_w[o * (kT * H) + t * H + u];
+                }
+        float* tail = head + kT * kHk * 64;
+        for (int hh = 0; hh < 2; ++hh)
+            for (int i = 0; i < 16; ++i) {
+                const int o = mfma32_row(i, hh);
+                if (o >= kL1) continue;
+                tail[hh * 16 + i] = lin1_b[o];
+                tail[32 + (0 * 2 + hh) * 16 + i] = lin2_w[0 * kL1 + o];
+                tail[32 + (1 * 2 + hh) * 16 + i] = lin2_w[1 * kL1 + o];
+            }
+        tail[96] = lin2_b[0];
+        tail[97] = lin2_b[1];
+    } else {
+        for (int t = 0; t < kT; ++t)
+            for (int cl = 0; cl < 2; ++cl)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int i = 0; i < 16; ++i) {
+                        const int u = mfma32_row(i, hh);
+                        if (u < H) head[((t * 2 + cl) * 2 + hh) * 16 + i] = lin_w[cl * (kT * H) + t * H + u];
+                    }
+        float* tail = head + kT * 2 * 2 * 16;
+        tail[0] = lin_b[0];
+        tail[1] = lin_b[1];
+    }
+    return VAD_OK;
+}
+
+extern "C" int vad_gru_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,
+                                   int hidden, int large, float* p_dev, uint8_t* decision_dev, int decision_mode,
+                                   float threshold, void* stream) {
+    return vad::forward(false, x_dev, n_windows, window_stride, blob_dev, hidden, large, p_dev, decision_dev,
+                        decision_mode, threshold, stream);
+}
+
+extern "C" int vad_lstm_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,
+                                    int hidden, int large, float* p_dev, uint8_t* decision_dev, int decision_mode,
+                                    float threshold, void* stream) {
+    return vad::forward(true, x_dev, n_windows, window_stride, blob_dev, hidden, large, p_dev, decision_dev,
+                        decision_mode, threshold, stream);
+}

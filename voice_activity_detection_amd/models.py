@@ -1,0 +1,213 @@
+"""``Net`` / ``DenseNet`` / ``MODEL_STACK`` with the reference's constructor and
+``forward`` signatures (core/models.py:9-81, 383-461, 465-514), evaluated by
+the HIP kernels of libvad_amd.so.
+
+The modules own ordinary ``torch.nn`` parameters under the reference's
+``state_dict`` names, so a reference checkpoint's state dict loads unchanged;
+the torch layers themselves are never called.  ``forward`` is inference only
+(eval-mode BatchNorm, Dropout off, no autograd), which is how the reference
+uses the models on this path (``net.eval()`` at core/train.py:410,558).
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .common import BATCH_SIZE, FEATURES, FRAMES
+
+DECIDE_ARGMAX = 0
+DECIDE_THRESHOLD = 1
+
+
+def _cuda_device():
+    if not torch.cuda.is_available():
+        raise _lib.VadError('no HIP device visible: the models have no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _np32(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+
+
+class _HipModule(nn.Module):
+    """Shared plumbing: packed-weight cache and the windows -> posterior call."""
+
+    def __init__(self):
+        super().__init__()
+        self._blob = None
+        self._blob_key = None
+
+    def _pack(self):                                   # -> numpy float32 blob
+        raise NotImplementedError
+
+    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+        raise NotImplementedError
+
+    def _weights_on(self, device):
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.state_dict().values())
+        if self._blob is None or self._blob_key != key:
+            self._blob = torch.from_numpy(self._pack()).to(device)
+            self._blob_key = key
+        return self._blob
+
+    def score(self, x, window_stride=None, n_windows=None, threshold=None, out=None, decisions=None):
+        """Posteriors for many windows without materialising them.
+
+        ``x``  float32 CUDA tensor.  A (B,30,24) batch, or -- with
+               ``window_stride`` given -- a packed (F,24) feature matrix from
+               which window w reads rows starting at float offset
+               ``w * window_stride`` (24 = the stride-1 sliding window of
+               core/train.py:566-570).
+        Returns ``(p (n,2) float32, decision (n,) uint8)``; the decision is the
+        argmax (core/train.py:605-607) or ``p[:,1] >= threshold``
+        (core/train.py:486-487).
+        """
+        L = _lib.lib()
+        if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError('x must be a contiguous float32 CUDA tensor')
+        if window_stride is None:
+            if x.dim() != 3 or x.size(1) != FRAMES or x.size(2) != FEATURES:
+                raise ValueError('expected a (B,%d,%d) batch, got %s' % (FRAMES, FEATURES, tuple(x.shape)))
+            window_stride, n = FRAMES * FEATURES, x.size(0)
+        else:
+            total = x.numel()
+            n = 0 if total < FRAMES * FEATURES else (total - FRAMES * FEATURES) // window_stride + 1
+            if n_windows is not None:
+                if n_windows > n:
+                    raise ValueError('n_windows %d exceeds the %d windows x can hold' % (n_windows, n))
+                n = n_windows
+        p = out if out is not None else torch.empty((n, 2), dtype=torch.float32, device=x.device)
+        d = decisions if decisions is not None else torch.empty((n,), dtype=torch.uint8, device=x.device)
+        if n == 0:
+            return p, d
+        blob = self._weights_on(x.device)
+        mode = DECIDE_ARGMAX if threshold is None else DECIDE_THRESHOLD
+        with torch.cuda.device(x.device):
+            _lib.check(self._launch(L, ctypes.c_void_p(x.data_ptr()), n, window_stride,
+                                    ctypes.c_void_p(blob.data_ptr()), ctypes.c_void_p(p.data_ptr()),
+                                    ctypes.c_void_p(d.data_ptr()), mode,
+                                    ctypes.c_float(0.0 if threshold is None else threshold),
+                                    _lib.current_stream()))
+        return p, d
+
+    def forward(self, x):
+        # core/models.py:44-47 widens 1-D / 2-D inputs to a batch of length-1 sequences; the
+        # reference's own view(-1, 900) then only works for 30-step windows, which is all it is fed.
+        if x.dim() != 3 or x.size(1) != FRAMES or x.size(2) != FEATURES:
+            raise RuntimeError('expected input of shape (batch, %d, %d), got %s'
+                               % (FRAMES, FEATURES, tuple(x.shape)))
+        x = x.detach().to(device=_cuda_device(), dtype=torch.float32).contiguous()   # core/models.py:50-51
+        return self.score(x)[0]
+
+
+class Net(_HipModule):
+    """core/models.py:9-81: 1-layer LSTM or GRU (24 -> 30), flatten, lin1+ReLU+lin2 or lin, softmax."""
+
+    def __init__(self, large=True, lstm=True):
+        super().__init__()
+        self.large = large
+        self.lstm = lstm
+        self.relu = nn.ReLU()
+        cls = nn.LSTM if lstm else nn.GRU
+        self.rnn = cls(input_size=FEATURES, hidden_size=FRAMES, num_layers=1, batch_first=True)
+        self.lin1 = nn.Linear(FRAMES ** 2, 26)
+        self.lin2 = nn.Linear(26, 2)
+        self.lin = nn.Linear(FRAMES ** 2, 2)
+        self.softmax = nn.Softmax(dim=1)
+
+    def _pack(self):
+        L = _lib.lib()
+        H = self.rnn.hidden_size
+        n = L.vad_net_blob_floats(int(self.lstm), int(self.large), H)
+        blob = np.zeros(n, np.float32)
+        a = {k: _np32(v) for k, v in self.state_dict().items()}
+        hp = _lib.host_ptr
+        _lib.check(L.vad_pack_net_weights(
+            int(self.lstm), int(self.large), H,
+            hp(a['rnn.weight_ih_l0']), hp(a['rnn.weight_hh_l0']), hp(a['rnn.bias_ih_l0']), hp(a['rnn.bias_hh_l0']),
+            hp(a['lin1.weight']), hp(a['lin1.bias']), hp(a['lin2.weight']), hp(a['lin2.bias']),
+            hp(a['lin.weight']), hp(a['lin.bias']), hp(blob), n))
+        return blob
+
+    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+        fn = L.vad_lstm_forward_f32 if self.lstm else L.vad_gru_forward_f32
+        return fn(x_ptr, n, stride, blob_ptr, self.rnn.hidden_size, int(self.large), p_ptr, d_ptr, mode, thr, stream)
+
+
+class _DenseSingle(nn.Module):                 # parameter container, core/models.py:333-348
+    def __init__(self, input_size, output_size, dropout, dilation, padding, kernel_size, stride):
+        super().__init__()
+        self.layer = nn.Sequential(
+            nn.Conv1d(input_size, output_size, kernel_size=kernel_size, padding=padding, stride=stride,
+                      dilation=dilation, bias=False),
+            nn.BatchNorm1d(output_size), nn.LeakyReLU(), nn.Dropout(p=dropout))
+
+
+class _DenseBlock(nn.Module):                  # core/models.py:351-364
+    def __init__(self, input_size, n_layers, growth_rate, dropout, dilation, padding, kernel_size, stride):
+        super().__init__()
+        self.block = nn.Sequential(*[
+            _DenseSingle(input_size + i * growth_rate, growth_rate, dropout, dilation, padding, kernel_size, stride)
+            for i in range(n_layers)])
+
+
+class _TransitionBlock(nn.Module):             # core/models.py:367-380
+    def __init__(self, input_size, output_size, dropout):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Conv1d(input_size, output_size, kernel_size=1, stride=1, bias=False), nn.BatchNorm1d(output_size),
+            nn.MaxPool1d(kernel_size=2, stride=2, padding=0), nn.LeakyReLU(), nn.Dropout(p=dropout))
+
+
+class DenseNet(_HipModule):
+    """core/models.py:383-461."""
+
+    def __init__(self, large=False):
+        super().__init__()
+        self.large = large
+        c0, nl, g, c1 = (48, 8, 4, 80) if large else (24, 6, 3, 42)
+        dropout = 0.4
+        self.cnn_in = nn.Sequential(
+            nn.Conv1d(in_channels=24, out_channels=c0, kernel_size=6, stride=1, padding=0, dilation=4, bias=False),
+            nn.BatchNorm1d(c0), nn.MaxPool1d(kernel_size=2, stride=2, padding=0), nn.LeakyReLU(),
+            nn.Dropout(p=dropout))
+        self.dense1 = _DenseBlock(input_size=c0, n_layers=nl, growth_rate=g, kernel_size=3, dilation=1, padding=1,
+                                  stride=1, dropout=dropout)
+        self.trans1 = _TransitionBlock(input_size=c1, output_size=c0, dropout=dropout)
+        self.dense2 = _DenseBlock(input_size=c0, n_layers=nl, growth_rate=g, kernel_size=3, dilation=1, padding=1,
+                                  stride=1, dropout=dropout)
+        self.cnn_out = nn.Sequential(
+            nn.Conv1d(in_channels=c1, out_channels=c1, kernel_size=1, stride=1, bias=False), nn.BatchNorm1d(c1),
+            nn.MaxPool1d(kernel_size=2, stride=2, padding=0), nn.LeakyReLU(), nn.Dropout(p=dropout))
+        self.out = nn.Linear(c1, 2, bias=False)
+
+    def _pack(self):
+        L = _lib.lib()
+        arrays = [_np32(v) for k, v in self.state_dict().items() if not k.endswith('num_batches_tracked')]
+        if len(arrays) != L.vad_densenet_tensor_count(int(self.large)):
+            raise _lib.VadError('unexpected DenseNet tensor count %d' % len(arrays))
+        ptrs = (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        n = L.vad_densenet_blob_floats(int(self.large))
+        blob = np.zeros(n, np.float32)
+        _lib.check(L.vad_pack_densenet_weights(int(self.large), ptrs, len(arrays), _lib.host_ptr(blob), n))
+        return blob
+
+    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+        return L.vad_densenet_forward_f32(x_ptr, n, stride, blob_ptr, int(self.large), p_ptr, d_ptr, mode, thr, stream)
+
+
+def _model_stack():
+    # names, descriptions and training kwargs as in core/models.py:465-514
+    return {
+        'net': {'desc': "LSTM, small, γ = 0", 'model': Net(large=False), 'kwargs': {'gamma': 0}},
+        'net_large': {'desc': "LSTM, large, γ = 2", 'model': Net(), 'kwargs': {'gamma': 2}},
+        'densenet': {'desc': "DenseNet, small, γ = 2", 'model': DenseNet(large=False),
+                     'kwargs': {'use_adam': False, 'lr': 1, 'momentum': 0.7, 'gamma': 2}},
+        'densenet_large': {'desc': "DenseNet, large, γ = 2", 'model': DenseNet(large=True),
+                           'kwargs': {'use_adam': False, 'lr': 1, 'momentum': 0.7, 'gamma': 2}},
+    }
+
+
+MODEL_STACK = _model_stack()
