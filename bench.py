@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Throughput of the VAD hot path on MI355X: audio-hours processed per second.
+
+One "step" is one pass of the whole path over one batch of synthetic audio that
+is already resident in HBM: int16 frames -> MFCC+delta (166-frame slices, as
+process_test_data cuts them) -> stride-1 30-frame windows -> GRU-30k forward ->
+posterior + decision per window, all left in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--hours H] [--model gru_large]
+
+For N > 1 the driver launches one rank per GPU through torch.distributed.run;
+every rank scores its own contiguous shard of the stream (weak scaling, no
+data-path collective); the timed region is bracketed by a barrier and the
+slowest rank's time is used.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES_PER_HOUR = 120000          # 3600 s / 0.03 s
+# Algorithmic work per unit, PyTorch-equivalent operation counts.
+FLOP_PER_WINDOW = {               # per 30 x 24 window
+    'gru_large': 30 * 24 * 90 * 2 + 30 * 30 * 90 * 2 + 30 * 30 * 12 + 900 * 26 * 2 + 26 * 2 * 2,
+    'gru_small': 30 * 24 * 90 * 2 + 30 * 30 * 90 * 2 + 30 * 30 * 12 + 900 * 2 * 2,
+    'lstm_large': 30 * 24 * 120 * 2 + 30 * 30 * 120 * 2 + 30 * 30 * 15 + 900 * 26 * 2 + 26 * 2 * 2,
+    'lstm_small': 30 * 24 * 120 * 2 + 30 * 30 * 120 * 2 + 30 * 30 * 15 + 900 * 2 * 2,
+    'densenet': 103_000,
+    'densenet_large': 262_000,
+}
+FRONTEND_BYTES_PER_FRAME = 480 * 2 + 24 * 4          # int16 in, 24 floats out
+FRONTEND_FLOP_PER_FRAME = 64_000                       # 2048-pt rfft + power + mel + DCT + delta
+PEAK_FP32_TFLOPS = 157.3                               # dense fp32 matrix = fp32 vector peak, MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def make_models(kind):
+    import voice_activity_detection_amd as pkg
+    from oracle import models_ref
+    ref = models_ref.make_model(kind)                  # seeded random weights (no checkpoints ship)
+    if kind.startswith('densenet'):
+        net = pkg.DenseNet(large=kind.endswith('large'))
+    else:
+        rnn, size = kind.split('_')
+        net = pkg.Net(large=(size == 'large'), lstm=(rnn == 'lstm'))
+    net.load_state_dict(ref.state_dict())
+    return net, ref
+
+
+def cpu_baseline(kind, budget_s=15.0):
+    """The CPU oracle (float64 numpy MFCC + torch CPU model, batch 2048) on a bounded sample."""
+    from oracle import pipeline_ref, synth_ref
+    _, ref = make_models(kind)
+    minute = synth_ref.synth_frames(0, 2000, seed=1337)            # 1 min = 2000 frames
+    pipeline_ref.vad_stream(ref, minute[:400])                     # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        pipeline_ref.vad_stream(ref, minute)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or reps >= 200:
+            break
+    hours = reps * 2000 / FRAMES_PER_HOUR
+    return {'value': hours / dt, 'unit': 'audio-hours/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d x 1 min synthetic audio (2000 frames, 1971 windows each), float64 numpy/scipy MFCC+delta '
+                      'in 166-frame slices + torch CPU %s, batch 2048; %.1f s of CPU work, host has %d CPUs'
+                      % (reps, kind, dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--hours', type=float, default=100.0, help='audio hours per GPU per step')
+    ap.add_argument('--model', default='gru_large', choices=sorted(FLOP_PER_WINDOW))
+    ap.add_argument('--slice', type=int, default=166, help='frames per MFCC slice (reference test path: 166)')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    import voice_activity_detection_amd as pkg
+    from voice_activity_detection_amd.sharding import shard_range
+    pkg.lib()
+    net, _ = make_models(args.model)
+
+    frames_per_gpu = int(round(args.hours * FRAMES_PER_HOUR))
+    first, n_frames = shard_range(frames_per_gpu * world, world, rank, args.slice)
+    stream = pkg.synth_stream(first, n_frames, seed=1337)          # generated on the device, outside the timing
+    ws = pkg.StreamWorkspace(n_frames, stream.device)
+    n_windows = n_frames - 29
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(events=None):
+        if events:
+            events[0].record()
+        pkg.mfcc_delta_stream(stream, n_frames, args.slice, out=ws.feat)
+        if events:
+            events[1].record()
+        net.score(ws.feat, window_stride=24, n_windows=n_windows, out=ws.p, decisions=ws.decision)
+        if events:
+            events[2].record()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(ev[k])
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([n_frames], dtype=torch.int64, device='cuda')
+        dist.all_reduce(tot)
+        total_frames = int(tot.item())
+    else:
+        total_frames = n_frames
+
+    if rank == 0:
+        fe_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        nn_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        assert bool(torch.isfinite(ws.p).all())
+        hours_per_step = total_frames / FRAMES_PER_HOUR
+        value = hours_per_step * args.steps / elapsed
+        flop = FLOP_PER_WINDOW[args.model] * n_windows
+        achieved = flop / (nn_ms * 1e-3) / 1e12
+        out = {
+            'metric': 'audio-hours processed/sec (MFCC+GRU-30k VAD)', 'value': value, 'unit': 'audio-hours/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s, %.0f h synthetic 16 kHz int16 audio per GPU, 12 MFCC + 12 delta, '
+                                   '%d-frame slices, stride-1 900 ms windows' % (args.model, args.hours, args.slice),
+                       'frames_per_gpu': n_frames, 'windows_per_gpu': n_windows, 'parallelism': 'shards x%d' % world},
+            'x_realtime_per_gpu': value * 3600.0 / world,
+            'roofline': {'bound': 'mfma', 'kernel': 'rnn_kernel (%s)' % args.model, 'achieved': achieved,
+                         'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
+                         'traffic': None, 'ms_per_launch': nn_ms,
+                         'flop_per_window': FLOP_PER_WINDOW[args.model], 'windows_per_launch': n_windows},
+            'frontend': {'kernel': 'mfcc_kernel + delta_kernel', 'ms_per_launch': fe_ms,
+                         'hbm_GBs': FRONTEND_BYTES_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e9,
+                         'hbm_frac': FRONTEND_BYTES_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         'fp32_TFLOPs': FRONTEND_FLOP_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e12,
+                         'fp32_frac': FRONTEND_FLOP_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS},
+        }
+        if world == 1 and not args.no_cpu:
+            out['cpu_baseline'] = cpu_baseline(args.model)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,49 @@
+"""Partitioning of one audio stream over ranks (one process per GPU).
+
+Every output frame depends on at most 3 earlier audio frames (MFCC alignment),
+the +-2 neighbouring MFCC rows of its own slice (delta) and the 29 following
+feature rows (window), and the reference already treats slices as independent
+calls (core/process_data.py:214-232).  Ranks therefore take contiguous,
+slice-aligned frame ranges, regenerate or re-read their own 3-frame lead-in and
+never exchange data; the per-window results are gathered on the host.
+"""
+from .common import FRAMES, SLICE_MAX
+
+
+def shard_range(total_frames, world, rank, slice_len=SLICE_MAX):
+    """(first_frame, n_frames) of ``rank``'s contiguous shard; boundaries fall on slice starts."""
+    if not 0 <= rank < world:
+        raise ValueError('rank %d outside world of %d' % (rank, world))
+    if slice_len <= 0:
+        slice_len = 1
+    n_slices = (total_frames + slice_len - 1) // slice_len
+    base, rem = divmod(n_slices, world)
+    s0 = rank * base + min(rank, rem)
+    s1 = s0 + base + (1 if rank < rem else 0)
+    first = min(s0 * slice_len, total_frames)
+    last = min(s1 * slice_len, total_frames)
+    return first, last - first
+
+
+def window_owner_ranges(total_frames, world, slice_len=SLICE_MAX, frames=FRAMES):
+    """[(first_window, n_windows)] per rank when every rank scores the windows that START in its
+    shard; a rank needs ``frames - 1`` feature rows of halo from its successor for the last ones."""
+    out = []
+    n_win = max(total_frames - frames + 1, 0)
+    for r in range(world):
+        first, n = shard_range(total_frames, world, r, slice_len)
+        lo = min(first, n_win)
+        hi = min(first + n, n_win)
+        out.append((lo, hi - lo))
+    return out
+
+
+def gather_posteriors(p_local, world, dist=None):
+    """Host-side gather of per-window posteriors (5 bytes/frame of result traffic; no device collective)."""
+    import torch
+    host = p_local.detach().cpu()
+    if dist is None or world == 1:
+        return host
+    parts = [None] * world
+    dist.all_gather_object(parts, host)
+    return torch.cat(parts, 0)
