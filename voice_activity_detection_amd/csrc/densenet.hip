@@ -1,14 +1,392 @@
-// DenseNet window classifier (core/models.py:383-461) -- placeholder until the kernel lands.
+// DenseNet window classifier for gfx950: DenseNet.forward of the reference
+// (core/models.py:383-461) in eval mode, BatchNorm folded into the convolutions.
+//
+// One wave owns 32 windows.  Its activations live in LDS as act[channel][position][window]
+// (window = lane & 31, so every access is bank-conflict free).
+//
+//  * Wide contractions -- the dilated stem convolution (K = 24 x 6 = 144) and the two 1x1
+//    convolutions (K = 42 or 80) -- run on the fp32 matrix cores exactly like the recurrent
+//    model: out^T (channel x window) = W (channel x k) . in^T (k x window) with
+//    v_mfma_f32_32x32x2_f32; the result has the window on the lane and 16 output channels in the
+//    accumulator registers, and each lane stores its channels straight to LDS.
+//  * The growth convolutions (3 or 4 output channels, kernel 3) would fill a tenth of a 32-row
+//    MFMA tile, so they run on the vector ALU: the two lane halves split the input channels,
+//    accumulate growth x positions partial sums each and combine them with one cross-half
+//    exchange per output.
+//
+// Order inside every stage is the reference's: convolution -> BatchNorm -> MaxPool(2) ->
+// LeakyReLU(0.01) (core/models.py:391-398); Dropout is the identity in eval mode.
+
+#include <math.h>
+#include <string.h>
+
 #include "vad_internal.h"
 
-extern "C" size_t vad_densenet_blob_floats(int large) { (void)large; return 0; }
-extern "C" int vad_densenet_tensor_count(int large) { return 5 * (3 + 2 * (large ? 8 : 6)) + 1; }
-extern "C" int vad_pack_densenet_weights(int, const float* const*, int, float*, size_t) {
-    vad::set_error("DenseNet kernel not built yet");
-    return VAD_EINVAL;
+namespace vad {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+constexpr int kF = VAD_FEATURES;    // 24 input channels
+constexpr int kTaps = 6;            // stem kernel size, dilation 4
+constexpr int kL1 = 5;              // positions inside dense block 1 (30 -> 10 -> pool 5)
+constexpr int kL2 = 2;              // positions inside dense block 2 (5 -> pool 2)
+
+template <bool LARGE>
+struct Dims {
+    static constexpr int c0 = LARGE ? 48 : 24;       // stem / transition channels
+    static constexpr int nl = LARGE ? 8 : 6;         // layers per dense block
+    static constexpr int g = LARGE ? 4 : 3;          // growth rate
+    static constexpr int c1 = c0 + nl * g;           // channels after a dense block (80 / 42)
+    static constexpr int mt0 = (c0 + 31) / 32;       // 32-row tiles covering c0
+    static constexpr int mt1 = (c1 + 31) / 32;       // 32-row tiles covering c1
+    static constexpr int ks1 = c1 / 2;               // k-steps of a 1x1 convolution over c1 channels
+};
+
+// Blob layout in floats.
+struct DnLayout {
+    int a_in, s_in;              // stem: A [mt0][6][12][64], shift [mt0][2][16]
+    int dense[2];                // dense block b: per layer [C_in][12] weights (o * 3 + tap, zero padded) + shift [4]
+    int a_tr, s_tr;              // transition: A [mt0][c1/2][64], shift [mt0][2][16]
+    int a_out, s_out;            // cnn_out:    A [mt1][c1/2][64], shift [mt1][2][16]
+    int w_fin;                   // out.weight: [mt1][2 classes][2 halves][16]
+    int total;
+};
+
+// Offset of growth layer i inside its dense block: layers 0..i-1 hold (c0 + g k) * 12 + 4 floats each.
+__host__ __device__ inline int dense_layer_offset(int c0, int g, int i) {
+    return i * (c0 * 12 + 4) + 6 * g * i * (i - 1);
 }
-extern "C" int vad_densenet_forward_f32(const float*, int64_t, int64_t, const float*, int, float*, uint8_t*, int, float,
-                                        void*) {
-    vad::set_error("DenseNet kernel not built yet");
-    return VAD_EINVAL;
+
+template <bool LARGE>
+__host__ __device__ inline DnLayout dn_layout() {
+    using D = Dims<LARGE>;
+    DnLayout L;
+    int o = 0;
+    L.a_in = o; o += D::mt0 * kTaps * 12 * 64;
+    L.s_in = o; o += D::mt0 * 32;
+    for (int b = 0; b < 2; ++b) {
+        L.dense[b] = o;
+        o += dense_layer_offset(D::c0, D::g, D::nl);
+    }
+    L.a_tr = o; o += D::mt0 * D::ks1 * 64;
+    L.s_tr = o; o += D::mt0 * 32;
+    L.a_out = o; o += D::mt1 * D::ks1 * 64;
+    L.s_out = o; o += D::mt1 * 32;
+    L.w_fin = o; o += D::mt1 * 2 * 2 * 16;
+    L.total = o;
+    return L;
+}
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.0f ? v : 0.01f * v; }
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ f32x16 load_shift(const float* p, int half) {
+    const float4* s = reinterpret_cast<const float4*>(p + half * 16);
+    f32x16 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = s[q];
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+    return r;
+}
+
+// One dense block: NL growth layers over L positions, appended channel by channel to act[].
+template <int NL, int G, int L>
+__device__ __forceinline__ void dense_block(float* act, const float* __restrict__ block_w, int c_first, int col,
+                                            int half) {
+    for (int layer = 0; layer < NL; ++layer) {
+        const int cin = c_first + G * layer;
+        const float* wl = block_w + dense_layer_offset(c_first, G, layer);
+        float acc[G][L];
+#pragma unroll
+        for (int o = 0; o < G; ++o)
+#pragma unroll
+            for (int l = 0; l < L; ++l) acc[o][l] = 0.0f;
+        for (int c = half; c < cin; c += 2) {
+            float a[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) a[l] = act[(c * L + l) * 32 + col];
+            const float4* wp = reinterpret_cast<const float4*>(wl + c * 12);
+            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
+            const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+            for (int o = 0; o < G; ++o)
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    float s = fmaf(w[o * 3 + 1], a[l], acc[o][l]);
+                    if (l > 0) s = fmaf(w[o * 3 + 0], a[l - 1], s);          // padding = 1
+                    if (l < L - 1) s = fmaf(w[o * 3 + 2], a[l + 1], s);
+                    acc[o][l] = s;
+                }
+        }
+        const float4 sh4 = *reinterpret_cast<const float4*>(wl + cin * 12);
+        const float sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+        for (int o = 0; o < G; ++o)
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const float v = lrelu(acc[o][l] + __shfl_xor(acc[o][l], 32, 64) + sh[o]);
+                if (half == 0) act[((cin + o) * L + l) * 32 + col] = v;
+            }
+        wave_lds_fence();
+    }
+}
+
+template <bool LARGE>
+__global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ x, long n_windows, long wstride,
+                                                      const float* __restrict__ blob, float* __restrict__ p_out,
+                                                      uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    using D = Dims<LARGE>;
+    __shared__ __align__(16) float act[D::c1 * kL1 * 32];
+    const DnLayout LY = dn_layout<LARGE>();
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const long w = (long)blockIdx.x * 32 + col;
+    const long wc = w < n_windows ? w : n_windows - 1;
+    const float* xw = x + wc * wstride + 12 * half;
+
+    // ---- stem: Conv1d(24 -> c0, k = 6, dilation 4) + BN + MaxPool(2) + LeakyReLU, 30 -> 10 -> 5 ----
+    for (int lp = 0; lp < kL1; ++lp) {
+        f32x16 acc_e[D::mt0], acc_o[D::mt0];
+#pragma unroll
+        for (int mt = 0; mt < D::mt0; ++mt) acc_e[mt] = acc_o[mt] = load_shift(blob + LY.s_in + mt * 32, half);
+        for (int j = 0; j < kTaps; ++j) {
+            const float* re = xw + (2 * lp + 4 * j) * kF;        // even position 2 lp reads row 2 lp + 4 j
+            const float4 e0 = *reinterpret_cast<const float4*>(re), e1 = *reinterpret_cast<const float4*>(re + 4),
+                         e2 = *reinterpret_cast<const float4*>(re + 8);
+            const float4 o0 = *reinterpret_cast<const float4*>(re + kF), o1 = *reinterpret_cast<const float4*>(re + kF + 4),
+                         o2 = *reinterpret_cast<const float4*>(re + kF + 8);
+            const float xe[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+            const float xo[12] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w};
+#pragma unroll
+            for (int s = 0; s < 12; ++s)
+#pragma unroll
+                for (int mt = 0; mt < D::mt0; ++mt) {
+                    const float a = blob[LY.a_in + ((mt * kTaps + j) * 12 + s) * 64 + lane];
+                    acc_e[mt] = MFMA(a, xe[s], acc_e[mt]);
+                    acc_o[mt] = MFMA(a, xo[s], acc_o[mt]);
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < D::mt0; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 32 * mt + mfma32_row(i, half);
+                if (c < D::c0) act[(c * kL1 + lp) * 32 + col] = lrelu(fmaxf(acc_e[mt][i], acc_o[mt][i]));
+            }
+    }
+    wave_lds_fence();
+
+    // ---- dense block 1 (5 positions) ----
+    dense_block<D::nl, D::g, kL1>(act, blob + LY.dense[0], D::c0, col, half);
+
+    // ---- transition: 1x1 conv c1 -> c0 + BN + MaxPool(2) + LeakyReLU, 5 -> 2 (position 4 is dropped) ----
+    f32x16 tr[D::mt0][kL2];
+#pragma unroll
+    for (int lp = 0; lp < kL2; ++lp) {
+        f32x16 acc_e[D::mt0], acc_o[D::mt0];
+#pragma unroll
+        for (int mt = 0; mt < D::mt0; ++mt) acc_e[mt] = acc_o[mt] = load_shift(blob + LY.s_tr + mt * 32, half);
+        for (int s = 0; s < D::ks1; ++s) {
+            const int c = 2 * s + half;
+            const float be = act[(c * kL1 + 2 * lp) * 32 + col];
+            const float bo = act[(c * kL1 + 2 * lp + 1) * 32 + col];
+#pragma unroll
+            for (int mt = 0; mt < D::mt0; ++mt) {
+                const float a = blob[LY.a_tr + (mt * D::ks1 + s) * 64 + lane];
+                acc_e[mt] = MFMA(a, be, acc_e[mt]);
+                acc_o[mt] = MFMA(a, bo, acc_o[mt]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < D::mt0; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tr[mt][lp][i] = lrelu(fmaxf(acc_e[mt][i], acc_o[mt][i]));
+    }
+    wave_lds_fence();                                           // all reads of block 1 are done
+#pragma unroll
+    for (int lp = 0; lp < kL2; ++lp)
+#pragma unroll
+        for (int mt = 0; mt < D::mt0; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 32 * mt + mfma32_row(i, half);
+                if (c < D::c0) act[(c * kL2 + lp) * 32 + col] = tr[mt][lp][i];
+            }
+    wave_lds_fence();
+
+    // ---- dense block 2 (2 positions) ----
+    dense_block<D::nl, D::g, kL2>(act, blob + LY.dense[1], D::c0, col, half);
+
+    // ---- cnn_out: 1x1 conv c1 -> c1 + BN + MaxPool(2) + LeakyReLU, 2 -> 1; then Linear(c1 -> 2) ----
+    float l0 = 0.0f, l1 = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < D::mt1; ++mt) {
+        f32x16 acc_e, acc_o;
+        acc_e = acc_o = load_shift(blob + LY.s_out + mt * 32, half);
+        for (int s = 0; s < D::ks1; ++s) {
+            const int c = 2 * s + half;
+            const float a = blob[LY.a_out + (mt * D::ks1 + s) * 64 + lane];
+            acc_e = MFMA(a, act[(c * kL2 + 0) * 32 + col], acc_e);
+            acc_o = MFMA(a, act[(c * kL2 + 1) * 32 + col], acc_o);
+        }
+        const float* wf0 = blob + LY.w_fin + ((mt * 2 + 0) * 2 + half) * 16;
+        const float* wf1 = blob + LY.w_fin + ((mt * 2 + 1) * 2 + half) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float y = lrelu(fmaxf(acc_e[i], acc_o[i]));    // padded channels carry zero weights below
+            l0 = fmaf(y, wf0[i], l0);
+            l1 = fmaf(y, wf1[i], l1);
+        }
+    }
+    l0 += __shfl_xor(l0, 32, 64);
+    l1 += __shfl_xor(l1, 32, 64);
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float inv = 1.0f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    if (half == 0 && w < n_windows) {
+        *reinterpret_cast<float2*>(p_out + 2 * w) = make_float2(p0, p1);
+        if (dec_out) dec_out[w] = (mode == VAD_DECIDE_THRESHOLD) ? (p1 >= threshold) : (p1 > p0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: BatchNorm folding and packing
+
+struct ConvBn {          // one Conv1d(bias=False) + BatchNorm1d pair of the state dict
+    const float *w, *gamma, *beta, *mean, *var;
+};
+
+template <bool LARGE>
+int pack(const float* const* t, float* blob) {
+    using D = Dims<LARGE>;
+    const DnLayout L = dn_layout<LARGE>();
+    memset(blob, 0, sizeof(float) * (size_t)L.total);
+    int idx = 0;
+    auto next = [&]() {
+        ConvBn c{t[idx], t[idx + 1], t[idx + 2], t[idx + 3], t[idx + 4]};
+        idx += 5;
+        return c;
+    };
+    auto scale = [](const ConvBn& c, int o) { return (double)c.gamma[o] / sqrt((double)c.var[o] + 1e-5); };
+    auto shift = [&](const ConvBn& c, int o) { return (double)c.beta[o] - (double)c.mean[o] * scale(c, o); };
+    auto put_shift_tiles = [&](const ConvBn& c, int n_out, int n_tiles, float* dst) {
+        for (int mt = 0; mt < n_tiles; ++mt)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int i = 0; i < 16; ++i) {
+                    const int o = 32 * mt + mfma32_row(i, hh);
+                    if (o < n_out) dst[mt * 32 + hh * 16 + i] = (float)shift(c, o);
+                }
+    };
+
+    // stem: weight (c0, 24, 6)
+    ConvBn cin = next();
+    for (int mt = 0; mt < D::mt0; ++mt)
+        for (int j = 0; j < kTaps; ++j)
+            for (int s = 0; s < 12; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int o = 32 * mt + (lane & 31), ci = s + 12 * (lane >> 5);
+                    if (o < D::c0)
+                        blob[L.a_in + ((mt * kTaps + j) * 12 + s) * 64 + lane] =
+                            (float)((double)cin.w[(o * kF + ci) * kTaps + j] * scale(cin, o));
+                }
+    put_shift_tiles(cin, D::c0, D::mt0, blob + L.s_in);
+
+    auto pack_dense = [&](int b) {
+        for (int i = 0; i < D::nl; ++i) {
+            ConvBn c = next();                       // weight (g, C_in, 3)
+            const int cn = D::c0 + D::g * i;
+            float* wl = blob + L.dense[b] + dense_layer_offset(D::c0, D::g, i);
+            for (int ch = 0; ch < cn; ++ch)
+                for (int o = 0; o < D::g; ++o)
+                    for (int j = 0; j < 3; ++j)
+                        wl[ch * 12 + o * 3 + j] = (float)((double)c.w[(o * cn + ch) * 3 + j] * scale(c, o));
+            for (int o = 0; o < D::g; ++o) wl[cn * 12 + o] = (float)shift(c, o);
+        }
+    };
+    auto pack_1x1 = [&](const ConvBn& c, int n_out, int n_tiles, float* a, float* s) {   // weight (n_out, c1, 1)
+        for (int mt = 0; mt < n_tiles; ++mt)
+            for (int ks = 0; ks < D::ks1; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int o = 32 * mt + (lane & 31), ch = 2 * ks + (lane >> 5);
+                    if (o < n_out) a[(mt * D::ks1 + ks) * 64 + lane] = (float)((double)c.w[o * D::c1 + ch] * scale(c, o));
+                }
+        put_shift_tiles(c, n_out, n_tiles, s);
+    };
+
+    pack_dense(0);
+    ConvBn tr = next();
+    pack_1x1(tr, D::c0, D::mt0, blob + L.a_tr, blob + L.s_tr);
+    pack_dense(1);
+    ConvBn co = next();
+    pack_1x1(co, D::c1, D::mt1, blob + L.a_out, blob + L.s_out);
+    const float* wout = t[idx];                      // out.weight (2, c1)
+    for (int mt = 0; mt < D::mt1; ++mt)
+        for (int cl = 0; cl < 2; ++cl)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int i = 0; i < 16; ++i) {
+                    const int ch = 32 * mt + mfma32_row(i, hh);
+                    if (ch < D::c1) blob[L.w_fin + ((mt * 2 + cl) * 2 + hh) * 16 + i] = wout[cl * D::c1 + ch];
+                }
+    return VAD_OK;
+}
+
+template <bool LARGE>
+int launch(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
+           float threshold, hipStream_t st) {
+    const long blocks = (n_windows + 31) / 32;
+    VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
+    hipLaunchKernelGGL(densenet_kernel<LARGE>, dim3((unsigned)blocks), dim3(64), 0, st, x, n_windows, wstride, blob, p,
+                       dec, mode, threshold);
+    VAD_HIP_CHECK(hipGetLastError());
+    return VAD_OK;
+}
+
+}  // namespace
+}  // namespace vad
+
+extern "C" size_t vad_densenet_blob_floats(int large) {
+    return (size_t)(large ? vad::dn_layout<true>().total : vad::dn_layout<false>().total);
+}
+
+extern "C" int vad_densenet_tensor_count(int large) { return 5 * (3 + 2 * (large ? 8 : 6)) + 1; }
+
+extern "C" int vad_pack_densenet_weights(int large, const float* const* tensors_host, int n_tensors, float* blob_host,
+                                         size_t blob_floats) {
+    using namespace vad;
+    VAD_REQUIRE(tensors_host && blob_host, "null pointer argument");
+    VAD_REQUIRE(n_tensors == vad_densenet_tensor_count(large), "expected %d tensors, got %d",
+                vad_densenet_tensor_count(large), n_tensors);
+    for (int i = 0; i < n_tensors; ++i) VAD_REQUIRE(tensors_host[i], "tensor %d is null", i);
+    VAD_REQUIRE(blob_floats >= vad_densenet_blob_floats(large), "blob too small: need %zu floats",
+                vad_densenet_blob_floats(large));
+    return large ? pack<true>(tensors_host, blob_host) : pack<false>(tensors_host, blob_host);
+}
+
+extern "C" int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                                        const float* blob_dev, int large, float* p_dev, uint8_t* decision_dev,
+                                        int decision_mode, float threshold, void* stream) {
+    using namespace vad;
+    VAD_REQUIRE(x_dev && blob_dev && p_dev, "null pointer argument");
+    VAD_REQUIRE(n_windows >= 0, "n_windows must be >= 0");
+    VAD_REQUIRE(window_stride >= 0 && (window_stride % 4) == 0, "window_stride must be a non-negative multiple of 4 floats");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0, "x_dev must be 16-byte aligned");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(p_dev) & 7) == 0, "p_dev must be 8-byte aligned");
+    VAD_REQUIRE(decision_mode == VAD_DECIDE_ARGMAX || decision_mode == VAD_DECIDE_THRESHOLD, "unknown decision_mode %d",
+                decision_mode);
+    if (n_windows == 0) return VAD_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    return large ? launch<true>(x_dev, n_windows, window_stride, blob_dev, p_dev, decision_dev, decision_mode, threshold, st)
+                 : launch<false>(x_dev, n_windows, window_stride, blob_dev, p_dev, decision_dev, decision_mode, threshold, st);
 }
