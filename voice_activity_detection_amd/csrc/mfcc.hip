@@ -124,26 +124,59 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kWaveLdsBytes = 16 * kExStride * 8 /*exchange / Z*/ + 1024 * 4 /*power*/ + 2 * 64 * 4 /*partials*/ +
-                              32 * 8 /*log energies*/;
+constexpr int kStageRows = kFramesPerBlock + 4;              // predecessor row + 16 frames + 3 trailing rows
+constexpr int kStageDwords = kStageRows * (kFrame / 2);       // int16 pairs
+constexpr int kWaveLdsBytes = 16 * kExStride * 8 /*exchange, Z, partial sums, log energies*/ +
+                              1024 * 4 /*power spectrum*/ + kFramesPerWave * 32 * 4 /*filter energies*/;
+constexpr int kSmemBytes = kStageDwords * 4 + kNFilt * kNCep * 8 + kWavesPerBlock * kWaveLdsBytes;
 
+// grid: blocks_per_slice blocks for each slice; a block owns 16 consecutive frames of ONE slice, so
+// its 20 input rows are contiguous whatever slice_stride is.  Wave w takes frames w, w+4, w+8, w+12.
 __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict__ in, const MfccTables* __restrict__ tab,
-                                                      long n_frames, long frames_per_slice, long slice_stride,
+                                                      long n_slices, long frames_per_slice, long last_slice_frames,
+                                                      long slice_stride, int blocks_per_slice,
                                                       float* __restrict__ out, long out_ld) {
-    __shared__ __align__(16) unsigned char smem[kWavesPerBlock * kWaveLdsBytes + kNFilt * kNCep * 8];
+    __shared__ __align__(16) unsigned char smem[kSmemBytes];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    unsigned char* wbase = smem + wave * kWaveLdsBytes;
+    int* stage = reinterpret_cast<int*>(smem);
+    double* dct_s = reinterpret_cast<double*>(smem + kStageDwords * 4);
+    unsigned char* wbase = smem + kStageDwords * 4 + kNFilt * kNCep * 8 + wave * kWaveLdsBytes;
     float2* ex = reinterpret_cast<float2*>(wbase);                          // 16 x 68 complex
-    float* pw = reinterpret_cast<float*>(wbase + 16 * kExStride * 8);        // 1024 floats
-    float* part_r = pw + 1024;
+    float* part_r = reinterpret_cast<float*>(wbase);                        // aliases ex once Z is consumed
     float* part_f = part_r + 64;
-    double* logv = reinterpret_cast<double*>(part_f + 64);
-    double* dct_s = reinterpret_cast<double*>(smem + kWavesPerBlock * kWaveLdsBytes);
+    double* logv = reinterpret_cast<double*>(wbase);                        // aliases ex in the tail
+    float* pw = reinterpret_cast<float*>(wbase + 16 * kExStride * 8);        // 1024 floats
+    float* en = pw + 1024;                                                   // [4 frames][32]
 
-    for (int i = threadIdx.x; i < kNFilt * kNCep; i += blockDim.x) dct_s[i] = (&tab->dct[0][0])[i];
-    __syncthreads();
+    const long s = blockIdx.x / blocks_per_slice;
+    const int j0 = (int)(blockIdx.x - s * blocks_per_slice) * kFramesPerBlock;
+    const long n_s = (s == n_slices - 1) ? last_slice_frames : frames_per_slice;
+    if (j0 >= n_s) return;                                                   // block-uniform
+
+    // ---- stage aligned rows j0-1 .. j0+18 of the slice (zeros outside it) ----
+    {
+        const int16_t* slice = in + s * slice_stride;
+        const long rows = n_s + VAD_ALIGN_FRAMES;
+        if ((reinterpret_cast<uintptr_t>(slice) & 15) == 0) {
+            const uint4* src = reinterpret_cast<const uint4*>(slice);
+            uint4* dst = reinterpret_cast<uint4*>(stage);
+            for (int i = threadIdx.x; i < kStageDwords / 4; i += 256) {
+                const int row = i / 60, c4 = i - row * 60;
+                const long ar = (long)j0 - 1 + row;
+                dst[i] = (ar >= 0 && ar < rows) ? src[ar * 60 + c4] : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const int* src = reinterpret_cast<const int*>(slice);
+            for (int i = threadIdx.x; i < kStageDwords; i += 256) {
+                const int row = i / 240, c = i - row * 240;
+                const long ar = (long)j0 - 1 + row;
+                stage[i] = (ar >= 0 && ar < rows) ? src[ar * 240 + c] : 0;
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < kNFilt * kNCep; i += 256) dct_s[i] = (&tab->dct[0][0])[i];
 
     // Loop-invariant per-lane constants.
     float2 tw1[15], tw2[15], twr[16];
@@ -158,6 +191,9 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
     const float run_b0 = (float)tab->run_b0[lane];
     const float run_b1 = (float)tab->run_b1[lane];
     const float run_inv = tab->run_inv[lane];
+    const int fl = lane < kNFilt ? lane : 0;
+    const int rise_first = tab->rise_first[fl], rise_n = tab->rise_n[fl];
+    const int fall_first = tab->fall_first[fl], fall_n = tab->fall_n[fl];
 
     const int r4 = lane & 3;
     const float sA = (r4 & 2) ? -1.0f : 1.0f;
@@ -167,31 +203,32 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
     const bool swp = (r4 >= 2);
     const int q2 = ((r4 & 1) << 1) | (r4 >> 1);
 
-    const long first = (long)blockIdx.x * kFramesPerBlock + wave;
-    for (int it = 0; it < kFramesPerWave; ++it) {
-        const long g = first + (long)it * kWavesPerBlock;
-        if (g >= n_frames) break;                           // wave-uniform
-        const long s = g / frames_per_slice;
-        const long j = g - s * frames_per_slice;
-        const int* src = reinterpret_cast<const int*>(in + s * slice_stride + j * kFrame);
+    __syncthreads();
 
-        // ---- load + pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj ----
+    int nfr = 0;                                            // frames this wave produced (wave-uniform)
+#pragma unroll 1
+    for (int it = 0; it < kFramesPerWave; ++it) {
+        const int jl = wave + it * kWavesPerBlock;          // frame index inside the block
+        if (j0 + jl >= n_s) break;
+        nfr = it + 1;
+
+        // ---- load + pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj.  Frame jl covers staged
+        // rows jl+1 .. jl+4; the sample one row (480 samples) earlier is 240 dwords back.  The row in
+        // front of a slice's first aligned row is staged as zeros, which leaves that row un-emphasised
+        // exactly as the reference's 2-D preemphasis does. ----
         float2 v[16];
+        {
+            const int* cur_p = stage + (jl + 1) * (kFrame / 2) + lane;
 #pragma unroll
-        for (int jj = 0; jj < 15; ++jj) {
-            const int n = lane + 64 * jj;
-            const int cur = src[n];
-            float x0 = (float)(short)(cur & 0xFFFF);
-            float x1 = (float)(cur >> 16);
-            // Sample 2n lies in aligned row 2n/480; row 0 of a slice has no predecessor.
-            if (j > 0 || n >= kFrame / 2) {
-                const int prv = src[n - kFrame / 2];
-                x0 = fmaf(-0.97f, (float)(short)(prv & 0xFFFF), x0);
-                x1 = fmaf(-0.97f, (float)(prv >> 16), x1);
+            for (int jj = 0; jj < 15; ++jj) {
+                const int cur = cur_p[64 * jj];
+                const int prv = cur_p[64 * jj - kFrame / 2];
+                const float x0 = fmaf(-0.97f, (float)(short)(prv & 0xFFFF), (float)(short)(cur & 0xFFFF));
+                const float x1 = fmaf(-0.97f, (float)(prv >> 16), (float)(cur >> 16));
+                v[jj] = make_float2(x0, x1);
             }
-            v[jj] = make_float2(x0, x1);
+            v[15] = make_float2(0.0f, 0.0f);                // samples 1920..2047 are zero padding
         }
-        v[15] = make_float2(0.0f, 0.0f);                    // samples 1920..2047 are zero padding
 
         // ---- pass 1 ----
         dft16(v);
@@ -251,42 +288,54 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
         }
         wave_lds_fence();
 
-        // ---- mel segments: each lane sums a run of <= 20 bins of one segment ----
+        // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the
+        // 20 reads issue back to back, lanes past their run add zeros) ----
         {
             float sr = 0.0f, sf = 0.0f;
-#pragma unroll 4
+#pragma unroll
             for (int i = 0; i < kMaxRun; ++i) {
-                if (i < run_count) {
-                    const int bin = run_start + i;
-                    const float p = pw[bin];
-                    const float fb = (float)bin;
-                    sr = fmaf(p, (fb - run_b0) * run_inv, sr);
-                    sf = fmaf(p, (run_b1 - fb) * run_inv, sf);
-                }
+                const int bin = min(run_start + i, 1023);
+                const float p = (i < run_count) ? pw[bin] : 0.0f;
+                const float fb = (float)bin;
+                sr = fmaf(p, (fb - run_b0) * run_inv, sr);
+                sf = fmaf(p, (run_b1 - fb) * run_inv, sf);
             }
-            part_r[lane] = sr;
+            part_r[lane] = sr;                                            // ex is free again (Z consumed)
             part_f[lane] = sf;
         }
         wave_lds_fence();
 
-        if (lane < kNFilt) {
-            double e = 0.0;
-            const int rf = tab->rise_first[lane], rn = tab->rise_n[lane];
-            const int ff = tab->fall_first[lane], fn = tab->fall_n[lane];
-            for (int i = 0; i < rn; ++i) e += (double)part_r[rf + i];
-            for (int i = 0; i < fn; ++i) e += (double)part_f[ff + i];
-            if (e == 0.0) e = 2.220446049250313e-16;        // psf.fbank zero-energy clamp
-            logv[lane] = log(e);
+        // ---- filter f = rising parts of segment f + falling parts of segment f+1, fixed order ----
+        {
+            float e = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) e += (i < rise_n) ? part_r[min(rise_first + i, 63)] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) e += (i < fall_n) ? part_f[min(fall_first + i, 63)] : 0.0f;
+            if (lane < 32) en[it * 32 + lane] = e;
         }
         wave_lds_fence();
+    }
 
-        if (lane < kNCep) {
+    // ---- tail for the wave's (up to) 4 frames at once: log of the 26 energies, lifted DCT-II ----
+#pragma unroll
+    for (int r = 0; r < kFramesPerWave / 2; ++r) {
+        const int it = 2 * r + (lane >> 5), f = lane & 31;
+        if (f < kNFilt && it < nfr) {
+            const float e = en[it * 32 + f];
+            logv[it * kNFilt + f] = log(e == 0.0f ? 2.220446049250313e-16 : (double)e);   // psf.fbank clamp
+        }
+    }
+    wave_lds_fence();
+    if (lane < kFramesPerWave * kNCep) {
+        const int it = lane / kNCep, k = lane - it * kNCep;
+        if (it < nfr) {
             double c = 0.0;
 #pragma unroll
-            for (int n = 0; n < kNFilt; ++n) c = fma(logv[n], dct_s[n * kNCep + lane], c);
-            out[g * out_ld + lane] = (float)c;
+            for (int n = 0; n < kNFilt; ++n) c = fma(logv[it * kNFilt + n], dct_s[n * kNCep + k], c);
+            const long g = s * frames_per_slice + j0 + wave + it * kWavesPerBlock;
+            out[g * out_ld + k] = (float)c;
         }
-        wave_lds_fence();
     }
 }
 
@@ -423,10 +472,12 @@ extern "C" int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, i
     VAD_HIP_CHECK(hipGetDevice(&dev));
     const long n_frames = (long)((n_slices - 1) * frames_per_slice + last_slice_frames);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long blocks = (n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
+    const long bps = (frames_per_slice + kFramesPerBlock - 1) / kFramesPerBlock;
+    const long blocks = bps * n_slices;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many frames for one launch");
-    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(256), 0, st, frames_dev, g_tables[dev], n_frames,
-                       (long)frames_per_slice, (long)slice_stride, mfcc_dev, (long)mfcc_ld);
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(256), 0, st, frames_dev, g_tables[dev], (long)n_slices,
+                       (long)frames_per_slice, (long)last_slice_frames, (long)slice_stride, (int)bps, mfcc_dev,
+                       (long)mfcc_ld);
     VAD_HIP_CHECK(hipGetLastError());
     const long dthreads = n_frames * kNCep;
     const long dblocks = (dthreads + 255) / 256;
