@@ -100,15 +100,17 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     import voice_activity_detection_amd as pkg
-    from voice_activity_detection_amd.sharding import shard_range
+    from voice_activity_detection_amd.sharding import shard_plan
     pkg.lib()
     net, _ = make_models(args.model)
 
     frames_per_gpu = int(round(args.hours * FRAMES_PER_HOUR))
-    first, n_frames = shard_range(frames_per_gpu * world, world, rank, args.slice)
-    stream = pkg.synth_stream(first, n_frames, seed=1337)          # generated on the device, outside the timing
+    # contiguous slice-aligned shard of one stream; the rank re-creates its own lead-in and halo,
+    # and scores exactly the windows that start inside its shard (no inter-rank traffic)
+    plan = shard_plan(frames_per_gpu * world, world, rank, args.slice)
+    n_frames, n_windows = plan['n_load'], plan['n_windows']
+    stream = pkg.synth_stream(plan['first'], n_frames, seed=1337)   # generated on the device, outside the timing
     ws = pkg.StreamWorkspace(n_frames, stream.device)
-    n_windows = n_frames - 29
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
@@ -140,11 +142,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([n_frames], dtype=torch.int64, device='cuda')
+        tot = torch.tensor([plan['n_own']], dtype=torch.int64, device='cuda')
         dist.all_reduce(tot)
         total_frames = int(tot.item())
     else:
-        total_frames = n_frames
+        total_frames = plan['n_own']
 
     if rank == 0:
         fe_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))

@@ -1,0 +1,82 @@
+"""Multi-rank path on CPU (gloo, world_size 2): slice-aligned sharding of one stream and the
+host-side gather of per-window posteriors.
+
+No GPU is present here, so each rank computes its shard with the CPU oracle as a stand-in for
+the device call; what is under test is the partitioning and gather logic of
+voice_activity_detection_amd.sharding: the gathered result must equal the single-process result
+bit for bit, because slices are independent and every rank carries its own halo.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import models_ref, pipeline_ref, synth_ref
+from voice_activity_detection_amd.sharding import (gather_posteriors, shard_plan, shard_range,
+                                                   window_owner_ranges)
+
+N_FRAMES = 166 * 5 + 40
+SLICE = 166
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_path):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    net = models_ref.make_model('gru_small')
+    plan = shard_plan(N_FRAMES, world, rank, SLICE)
+    first, nw, w0 = plan['first'], plan['n_windows'], plan['first_window']
+    # the shard plus its lead-in (3 alignment frames) and its halo (29 window rows + 2 delta rows)
+    lead = min(first, 3)
+    frames = synth_ref.synth_frames(first - lead, plan['n_load'] + lead, seed=1337)
+    align = np.zeros((3, 480), np.int16)
+    if lead:
+        align[3 - lead:] = frames[:lead]
+    feat = pipeline_ref.features_sliced(frames[lead:], SLICE, first_align=align)
+    p = pipeline_ref.score_windows(net, pipeline_ref.windows(feat))[:nw]
+    assert len(p) == nw and w0 == min(first, N_FRAMES - 29)
+    full = gather_posteriors(torch.from_numpy(p), world, dist)
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_reproduce_single_process(tmp_path):
+    out = str(tmp_path / 'gathered.npy')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    gathered = np.load(out)
+    net = models_ref.make_model('gru_small')
+    _, p_ref, _ = pipeline_ref.vad_stream(net, synth_ref.synth_frames(0, N_FRAMES, seed=1337), SLICE)
+    assert gathered.shape == p_ref.shape == (N_FRAMES - 29, 2)
+    np.testing.assert_array_equal(gathered, p_ref)
+
+
+@pytest.mark.parametrize('world', [1, 2, 3, 4, 8])
+@pytest.mark.parametrize('total', [1, 29, 30, 166, 167, 1000, 12_000_000])
+def test_shard_ranges_tile_the_stream(world, total):
+    ranges = [shard_range(total, world, r, SLICE) for r in range(world)]
+    pos = 0
+    for first, n in ranges:
+        assert first == pos and n >= 0
+        assert first % SLICE == 0 or first == total
+        pos += n
+    assert pos == total
+    wins = window_owner_ranges(total, world, SLICE)
+    assert sum(n for _, n in wins) == max(total - 29, 0)
+    if world > 1 and total >= SLICE * world:
+        sizes = [n for _, n in ranges]
+        assert max(sizes) - min(sizes) < 2 * SLICE

@@ -10,7 +10,7 @@ from .common import (ALIGN_FRAMES, BATCH_SIZE, FEATURES, FRAME_SIZE, FRAMES, SAM
 from .models import MODEL_STACK, DenseNet, Net
 from .process_data import (add_noise, mfcc_delta_slices, mfcc_delta_stream, overlay, process_test_frames)
 from .stream import StreamWorkspace, vad_stream
-from .sharding import gather_posteriors, shard_range, window_owner_ranges
+from .sharding import HALO_FRAMES, gather_posteriors, shard_plan, shard_range, window_owner_ranges
 from .synth import synth_audio, synth_stream
 
 __all__ = ['VadError', 'build', 'lib', 'Net', 'DenseNet', 'MODEL_STACK', 'process_test_frames', 'add_noise',

@@ -20,10 +20,20 @@
 // non-linearities are plain per-lane VALU work that overlaps the MFMAs of the
 // other wave on the SIMD.
 //
-// The first Linear layer (900 -> 26) is accumulated step by step as one more
-// 32-row tile,  L^T += W1[:, 30 t + u] . h_t^T , so the (B, 30, 30) tensor of
-// hidden states is never materialised.  fp32 MFMA is a k-ordered fmaf chain:
-// results are exact fp32, no reduced-precision operand anywhere.
+// The first Linear layer (900 -> 26, or 900 -> 2 for the small head) is
+// accumulated step by step as one more 32-row tile,
+// L^T += W1[:, 30 t + u] . h_t^T , so the (B, 30, 30) tensor of hidden states
+// is never materialised.  fp32 MFMA is a k-ordered fmaf chain: results are
+// exact fp32, no reduced-precision operand anywhere.
+//
+// Two kernels share this cell:
+//   rnn_kernel         any window stride; the input projection W_ih x_t is part of each
+//                      step's accumulation chain (100 MFMAs per GRU step).
+//   rnn_stream_kernel  stride-1 windows over a packed (F, 24) matrix: a feature row is shared
+//                      by up to 30 windows, so a block first projects each of its rows once
+//                      (bias + W_ih x, the same fmaf chain) into LDS and the steps start their
+//                      accumulators from there (64 MFMAs per GRU step).  Results are bit-identical
+//                      to rnn_kernel.
 
 #include <math.h>
 #include <string.h>
@@ -41,19 +51,18 @@ constexpr int kHp = 32;             // padded hidden size (one 32-row tile per g
 constexpr int kHk = kHp / 2;        // 16 k-steps of the recurrent product
 constexpr int kL1 = 26;             // lin1 outputs
 constexpr int kWindowsPerWave = 32;
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 4;   // rnn_kernel
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Blob layout in floats; shared by the host packer and the kernel.
+// Blob layout in floats; shared by the host packer and the kernels.
 struct NetLayout {
     int gates;        // 3 GRU, 4 LSTM
     int a_ih;         // [gates][12][64]   A operands of the input projection
     int a_hh;         // [gates][16][64]   A operands of the recurrent product
     int cb;           // [4][2][16]        accumulator initial values (biases), per lane half
-    int lds_floats;   // everything above is staged in LDS
-    int head;         // large: a1 [30][16][64], b1e [2][16], w2e [2][2][16], b2 [4]
-                      // small: wl [30][2][2][16] (class, half, reg), bl [4]
+    int head;         // a1 [30][16][64]   A operands of lin1 (large) or lin (small, rows 0-1)
+    int tail;         // large: b1e [2][16], w2e [2][2][16], b2 [2] (+2 pad); small: bl [2] (+2 pad)
     int total;
 };
 
@@ -63,9 +72,9 @@ __host__ __device__ inline NetLayout net_layout(bool lstm, bool large) {
     L.a_ih = 0;
     L.a_hh = L.a_ih + L.gates * kKs * 64;
     L.cb = L.a_hh + L.gates * kHk * 64;
-    L.lds_floats = L.cb + 4 * 2 * 16;
-    L.head = L.lds_floats;
-    L.total = L.head + (large ? (kT * kHk * 64 + 2 * 16 + 2 * 2 * 16 + 4) : (kT * 2 * 2 * 16 + 4));
+    L.head = L.cb + 4 * 2 * 16;
+    L.tail = L.head + kT * kHk * 64;
+    L.total = L.tail + (large ? (2 * 16 + 2 * 2 * 16 + 4) : 4);
     return L;
 }
 
@@ -78,6 +87,94 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+__device__ __forceinline__ f32x16 load16(const float* p) {      // 16 consecutive floats, 16-byte aligned
+    const float4* s = reinterpret_cast<const float4*>(p);
+    f32x16 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = s[q];
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+    return r;
+}
+
+// Recurrent product for one step: acc += W_hh . h  (GRU keeps W_hn h + b_hn apart in acc[3]).
+template <bool LSTM>
+__device__ __forceinline__ void recurrent_mfma(f32x16 (&acc)[4], const f32x16& h, const float* a_hh, int lane) {
+#pragma unroll
+    for (int i = 0; i < kHk; ++i) {
+        const float hv = h[i];
+        if (LSTM) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = MFMA(a_hh[(g * kHk + i) * 64 + lane], hv, acc[g]);
+        } else {
+            acc[0] = MFMA(a_hh[(0 * kHk + i) * 64 + lane], hv, acc[0]);
+            acc[1] = MFMA(a_hh[(1 * kHk + i) * 64 + lane], hv, acc[1]);
+            acc[3] = MFMA(a_hh[(2 * kHk + i) * 64 + lane], hv, acc[3]);
+        }
+    }
+}
+
+// Gate non-linearities, elementwise in (unit, window).
+template <bool LSTM>
+__device__ __forceinline__ void gate_update(const f32x16 (&acc)[4], f32x16& h, f32x16& c) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (LSTM) {
+            const float ig = fast_sigmoid(acc[0][i]);
+            const float fg = fast_sigmoid(acc[1][i]);
+            const float gg = fast_tanh(acc[2][i]);
+            const float og = fast_sigmoid(acc[3][i]);
+            const float cn = fmaf(fg, c[i], ig * gg);
+            c[i] = cn;
+            h[i] = og * fast_tanh(cn);
+        } else {
+            const float r = fast_sigmoid(acc[0][i]);
+            const float z = fast_sigmoid(acc[1][i]);
+            const float n = fast_tanh(fmaf(r, acc[3][i], acc[2][i]));
+            h[i] = fmaf(z, h[i] - n, n);
+        }
+    }
+}
+
+// (ReLU, lin2) or the bias of lin; softmax over the 2 classes; decision.
+template <bool LARGE>
+__device__ __forceinline__ void head_epilogue(const f32x16& lacc, const float* __restrict__ tail, int half, long w,
+                                              long n_windows, float* __restrict__ p_out, uint8_t* __restrict__ dec_out,
+                                              int mode, float threshold) {
+    float l0, l1;
+    if (LARGE) {
+        const float* b1e = tail + half * 16;
+        const float* w2a = tail + 32 + (0 * 2 + half) * 16;
+        const float* w2b = tail + 32 + (1 * 2 + half) * 16;
+        l0 = l1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = fmaxf(lacc[i] + b1e[i], 0.0f);
+            l0 = fmaf(v, w2a[i], l0);
+            l1 = fmaf(v, w2b[i], l1);
+        }
+        l0 += __shfl_xor(l0, 32, 64);
+        l1 += __shfl_xor(l1, 32, 64);
+        l0 += tail[96];
+        l1 += tail[97];
+    } else {
+        l0 = lacc[0] + tail[0];          // rows 0 and 1 of the tile live in lane half 0
+        l1 = lacc[1] + tail[1];
+    }
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float inv = 1.0f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    if (half == 0 && w < n_windows) {
+        *reinterpret_cast<float2*>(p_out + 2 * w) = make_float2(p0, p1);
+        if (dec_out) dec_out[w] = (mode == VAD_DECIDE_THRESHOLD) ? (p1 >= threshold) : (p1 > p0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// any window stride
+
 template <bool LSTM, bool LARGE>
 __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x, long n_windows, long wstride,
                                                      const float* __restrict__ blob, float* __restrict__ p_out,
@@ -85,14 +182,12 @@ __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x
     constexpr int G = LSTM ? 4 : 3;
     extern __shared__ __align__(16) float lds[];
     const NetLayout L = net_layout(LSTM, LARGE);
-    const int small_head_floats = LARGE ? 0 : kT * 2 * 2 * 16;
-    for (int i = threadIdx.x; i < L.lds_floats + small_head_floats; i += blockDim.x) lds[i] = blob[i];
+    for (int i = threadIdx.x; i < L.head; i += blockDim.x) lds[i] = blob[i];
     __syncthreads();
     const float* a_ih = lds + L.a_ih;
     const float* a_hh = lds + L.a_hh;
     const float* cb = lds + L.cb;
-    const float* wl = lds + L.head;                 // small head only
-    const float* a1 = blob + L.head;                // large head only (stays in L2)
+    const float* a1 = blob + L.head;                 // stays in L2
 
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -106,7 +201,6 @@ __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x
     f32x16 h, c, lacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { h[i] = 0.0f; c[i] = 0.0f; lacc[i] = 0.0f; }
-    float l0 = 0.0f, l1 = 0.0f;
 
     float4 xa = *reinterpret_cast<const float4*>(xw);
     float4 xb = *reinterpret_cast<const float4*>(xw + 4);
@@ -120,22 +214,9 @@ __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x
             xb = *reinterpret_cast<const float4*>(xw + tn * kF + 4);
             xc = *reinterpret_cast<const float4*>(xw + tn * kF + 8);
         }
-        float a1v[16];
-        if (LARGE) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
-        }
-
         f32x16 acc[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4* src = reinterpret_cast<const float4*>(cb + (a * 2 + half) * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = src[q];
-                acc[a][4 * q] = v.x; acc[a][4 * q + 1] = v.y; acc[a][4 * q + 2] = v.z; acc[a][4 * q + 3] = v.w;
-            }
-        }
+        for (int a = 0; a < 4; ++a) acc[a] = load16(cb + (a * 2 + half) * 16);
 
         // input projection, K = 24: k-step s takes feature s from lane half 0 and s + 12 from half 1
 #pragma unroll
@@ -143,89 +224,130 @@ __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x
 #pragma unroll
             for (int g = 0; g < G; ++g) acc[g] = MFMA(a_ih[(g * kKs + s) * 64 + lane], xv[s], acc[g]);
         }
-        // recurrent product, K = 32: k-step i takes unit u(i, half) = the lane's own h[i]
-        if (t > 0) {
+        // recurrent product, K = 32: k-step i takes unit u(i, half) = the lane's own h[i]; h_0 = 0
+        if (t > 0) recurrent_mfma<LSTM>(acc, h, a_hh, lane);
+        float a1v[16];                                   // issued here, consumed after the gate math
 #pragma unroll
-            for (int i = 0; i < kHk; ++i) {
-                const float hv = h[i];
-                if (LSTM) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = MFMA(a_hh[(g * kHk + i) * 64 + lane], hv, acc[g]);
-                } else {
-                    acc[0] = MFMA(a_hh[(0 * kHk + i) * 64 + lane], hv, acc[0]);
-                    acc[1] = MFMA(a_hh[(1 * kHk + i) * 64 + lane], hv, acc[1]);
-                    acc[3] = MFMA(a_hh[(2 * kHk + i) * 64 + lane], hv, acc[3]);   // W_hn h + b_hn kept apart
-                }
-            }
-        }
-
-        // gate non-linearities, elementwise in (unit, window)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (LSTM) {
-                const float ig = fast_sigmoid(acc[0][i]);
-                const float fg = fast_sigmoid(acc[1][i]);
-                const float gg = fast_tanh(acc[2][i]);
-                const float og = fast_sigmoid(acc[3][i]);
-                const float cn = fmaf(fg, c[i], ig * gg);
-                c[i] = cn;
-                h[i] = og * fast_tanh(cn);
-            } else {
-                const float r = fast_sigmoid(acc[0][i]);
-                const float z = fast_sigmoid(acc[1][i]);
-                const float n = fast_tanh(fmaf(r, acc[3][i], acc[2][i]));
-                h[i] = fmaf(z, h[i] - n, n);
-            }
-        }
-
+        for (int i = 0; i < 16; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
+        gate_update<LSTM>(acc, h, c);
         // head: flatten index is t * H + unit
-        if (LARGE) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) lacc = MFMA(a1v[i], h[i], lacc);
-        } else {
-            const float* w0 = wl + ((t * 2 + 0) * 2 + half) * 16;
-            const float* w1 = wl + ((t * 2 + 1) * 2 + half) * 16;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                l0 = fmaf(h[i], w0[i], l0);
-                l1 = fmaf(h[i], w1[i], l1);
-            }
-        }
+        for (int i = 0; i < 16; ++i) lacc = MFMA(a1v[i], h[i], lacc);
     }
-
-    // epilogue: (ReLU, lin2) or the tail of lin; softmax over the 2 classes; decision
-    const float* tail = blob + L.head + (LARGE ? kT * kHk * 64 : kT * 2 * 2 * 16);
-    if (LARGE) {
-        const float* b1e = tail + half * 16;
-        const float* w2a = tail + 32 + (0 * 2 + half) * 16;
-        const float* w2b = tail + 32 + (1 * 2 + half) * 16;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = fmaxf(lacc[i] + b1e[i], 0.0f);
-            l0 = fmaf(v, w2a[i], l0);
-            l1 = fmaf(v, w2b[i], l1);
-        }
-        tail += 32 + 64;
-    }
-    l0 += __shfl_xor(l0, 32, 64);
-    l1 += __shfl_xor(l1, 32, 64);
-    l0 += tail[0];
-    l1 += tail[1];
-    const float m = fmaxf(l0, l1);
-    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-    const float inv = 1.0f / (e0 + e1);
-    const float p0 = e0 * inv, p1 = e1 * inv;
-    if (half == 0 && w < n_windows) {
-        *reinterpret_cast<float2*>(p_out + 2 * w) = make_float2(p0, p1);
-        if (dec_out) dec_out[w] = (mode == VAD_DECIDE_THRESHOLD) ? (p1 >= threshold) : (p1 > p0);
-    }
+    head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
 }
+
+// ---------------------------------------------------------------------------------------------
+// stride-1 windows over a packed (F, 24) matrix, input projection hoisted per row
+
+template <bool LSTM>
+struct StreamCfg {
+    static constexpr int G = LSTM ? 4 : 3;
+    static constexpr int waves = LSTM ? 7 : 8;                  // LDS-limited: one block per CU
+    static constexpr int windows = waves * kWindowsPerWave;     // 224 / 256 windows per block
+    static constexpr int tiles = waves + 1;                     // 32-row tiles covering windows + 29 rows
+    static constexpr int rs = G * 32 + 4;                       // row stride in floats: 100 / 132, keeps
+                                                                // ds_read_b128 of 16 lanes on distinct banks
+    static constexpr int gi_floats = tiles * 32 * rs;
+    static constexpr int lds_floats = gi_floats + G * kHk * 64 + 4 * 2 * 16;
+};
+
+template <bool LSTM, bool LARGE>
+__global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel(
+    const float* __restrict__ feat, long n_windows, const float* __restrict__ blob, float* __restrict__ p_out,
+    uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    using C = StreamCfg<LSTM>;
+    constexpr int G = C::G;
+    extern __shared__ __align__(16) float lds[];
+    const NetLayout L = net_layout(LSTM, LARGE);
+    float* gi = lds;                                             // [tiles * 32 rows][rs]
+    float* a_hh = lds + C::gi_floats;
+    float* cb = a_hh + G * kHk * 64;
+    for (int i = threadIdx.x; i < G * kHk * 64 + 4 * 2 * 16; i += C::waves * 64) a_hh[i] = blob[L.a_hh + i];
+
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    const long w0 = (long)blockIdx.x * C::windows;
+    const long last_row = n_windows + kT - 2;                    // the matrix has n_windows + 29 rows
+
+    // ---- phase 1: gi[row][gate * 32 + unit] = bias + W_ih x_row, one (row tile, gate) task at a time ----
+    for (int task = wave; task < C::tiles * G; task += C::waves) {
+        const int tile = task / G, g = task - tile * G;
+        long row = w0 + tile * 32 + col;
+        if (row > last_row) row = last_row;
+        const float* xr = feat + row * kF + 12 * half;
+        const float4 xa = *reinterpret_cast<const float4*>(xr), xb = *reinterpret_cast<const float4*>(xr + 4),
+                     xc = *reinterpret_cast<const float4*>(xr + 8);
+        const float xv[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+        f32x16 acc = load16(blob + L.cb + (g * 2 + half) * 16);
+#pragma unroll
+        for (int s = 0; s < kKs; ++s) acc = MFMA(blob[L.a_ih + (g * kKs + s) * 64 + lane], xv[s], acc);
+        float* dst = gi + (tile * 32 + col) * C::rs + g * 32 + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    __syncthreads();
+
+    // ---- phase 2: 30 steps for the wave's 32 windows ----
+    const long w = w0 + wave * kWindowsPerWave + col;
+    if (w0 + wave * kWindowsPerWave >= n_windows) return;       // wave-uniform, after the only barrier
+    const float* a1 = blob + L.head;
+    f32x16 h, c, lacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { h[i] = 0.0f; c[i] = 0.0f; lacc[i] = 0.0f; }
+    const float* girow = gi + (wave * kWindowsPerWave + col) * C::rs + 4 * half;
+
+    for (int t = 0; t < kT; ++t) {
+        float a1v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
+        f32x16 acc[4];
+        const float* src = girow + t * C::rs;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(src + g * 32 + 8 * q);
+                acc[g][4 * q] = v.x; acc[g][4 * q + 1] = v.y; acc[g][4 * q + 2] = v.z; acc[g][4 * q + 3] = v.w;
+            }
+        if (!LSTM) acc[3] = load16(cb + (3 * 2 + half) * 16);    // b_hn
+        if (t > 0) recurrent_mfma<LSTM>(acc, h, a_hh, lane);
+        gate_update<LSTM>(acc, h, c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lacc = MFMA(a1v[i], h[i], lacc);
+    }
+    head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
 
 template <bool LSTM, bool LARGE>
 int launch(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
            float threshold, hipStream_t st) {
+    if (wstride == kF) {
+        using C = StreamCfg<LSTM>;
+        static bool attr_set[64] = {false};                      // per device; >64 KB of dynamic LDS needs opting in
+        int dev = 0;
+        VAD_HIP_CHECK(hipGetDevice(&dev));
+        const size_t lds_bytes = (size_t)C::lds_floats * sizeof(float);
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+            VAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_stream_kernel<LSTM, LARGE>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_set[dev] = true;
+        }
+        const long blocks = (n_windows + C::windows - 1) / C::windows;
+        VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
+        hipLaunchKernelGGL((rnn_stream_kernel<LSTM, LARGE>), dim3((unsigned)blocks), dim3(C::waves * 64), lds_bytes, st, x,
+                           n_windows, blob, p, dec, mode, threshold);
+        VAD_HIP_CHECK(hipGetLastError());
+        return VAD_OK;
+    }
     const NetLayout L = net_layout(LSTM, LARGE);
-    const size_t lds_bytes = (size_t)(L.lds_floats + (LARGE ? 0 : kT * 2 * 2 * 16)) * sizeof(float);
+    const size_t lds_bytes = (size_t)L.head * sizeof(float);
     const long per_block = (long)kWindowsPerWave * kWavesPerBlock;
     const long blocks = (n_windows + per_block - 1) / per_block;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
@@ -242,6 +364,7 @@ int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const
     VAD_REQUIRE(n_windows >= 0, "n_windows must be >= 0");
     VAD_REQUIRE(wstride >= 0 && (wstride % 4) == 0, "window_stride must be a non-negative multiple of 4 floats");
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x_dev must be 16-byte aligned");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(blob) & 15) == 0, "blob_dev must be 16-byte aligned");
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(p) & 7) == 0, "p_dev must be 8-byte aligned");
     VAD_REQUIRE(mode == VAD_DECIDE_ARGMAX || mode == VAD_DECIDE_THRESHOLD, "unknown decision_mode %d", mode);
     if (n_windows == 0) return VAD_OK;
@@ -300,15 +423,18 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
                 cb[(3 * 2 + hh) * 16 + i] = b_hh[2 * H + u];                      // W_hn h + b_hn
             }
         }
+    // head: rows of lin1 (26) or lin (2) as one 32-row A tile per step
+    const float* hw = large ? lin1_w : lin_w;
+    const int rows = large ? kL1 : 2;
     float* head = blob + L.head;
+    for (int t = 0; t < kT; ++t)
+        for (int i = 0; i < kHk; ++i)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int o = lane & 31, u = mfma32_row(i, lane >> 5);
+                if (o < rows && u < H) head[(t * kHk + i) * 64 + lane] = hw[o * (kT * H) + t * H + u];
+            }
+    float* tail = blob + L.tail;
     if (large) {
-        for (int t = 0; t < kT; ++t)
-            for (int i = 0; i < kHk; ++i)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int o = lane & 31, u = mfma32_row(i, lane >> 5);
-                    if (o < kL1 && u < H) head[(t * kHk + i) * 64 + lane] = lin1_w[o * (kT * H) + t * H + u];
-                }
-        float* tail = head + kT * kHk * 64;
         for (int hh = 0; hh < 2; ++hh)
             for (int i = 0; i < 16; ++i) {
                 const int o = mfma32_row(i, hh);
@@ -320,14 +446,6 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
         tail[96] = lin2_b[0];
         tail[97] = lin2_b[1];
     } else {
-        for (int t = 0; t < kT; ++t)
-            for (int cl = 0; cl < 2; ++cl)
-                for (int hh = 0; hh < 2; ++hh)
-                    for (int i = 0; i < 16; ++i) {
-                        const int u = mfma32_row(i, hh);
-                        if (u < H) head[((t * 2 + cl) * 2 + hh) * 16 + i] = lin_w[cl * (kT * H) + t * H + u];
-                    }
-        float* tail = head + kT * 2 * 2 * 16;
         tail[0] = lin_b[0];
         tail[1] = lin_b[1];
     }

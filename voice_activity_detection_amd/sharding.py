@@ -9,6 +9,11 @@ never exchange data; the per-window results are gathered on the host.
 """
 from .common import FRAMES, SLICE_MAX
 
+# Frames a rank needs beyond its own shard to score every window that STARTS in the shard: 29 more
+# feature rows for the window, and 2 more MFCC rows so that the deltas of those 29 rows see their real
+# neighbours rather than the replicated edge of a truncated slice.
+HALO_FRAMES = (FRAMES - 1) + 2
+
 
 def shard_range(total_frames, world, rank, slice_len=SLICE_MAX):
     """(first_frame, n_frames) of ``rank``'s contiguous shard; boundaries fall on slice starts."""
@@ -23,6 +28,20 @@ def shard_range(total_frames, world, rank, slice_len=SLICE_MAX):
     first = min(s0 * slice_len, total_frames)
     last = min(s1 * slice_len, total_frames)
     return first, last - first
+
+
+def shard_plan(total_frames, world, rank, slice_len=SLICE_MAX, frames=FRAMES):
+    """Everything one rank needs: dict with
+    ``first``        first frame of the shard (a slice start),
+    ``n_own``        frames of the shard,
+    ``n_load``       frames to run the front end over (shard + halo, clipped to the stream),
+    ``first_window`` / ``n_windows``  the windows that start in the shard.
+    Feature rows ``[0, n_windows + frames - 1)`` of the loaded range are exact; the last rows of
+    the halo may carry a truncated slice's delta edge and are never read by those windows."""
+    first, n_own = shard_range(total_frames, world, rank, slice_len)
+    n_load = min(n_own + HALO_FRAMES, total_frames - first) if n_own else 0
+    first_window, n_windows = window_owner_ranges(total_frames, world, slice_len, frames)[rank]
+    return {'first': first, 'n_own': n_own, 'n_load': n_load, 'first_window': first_window, 'n_windows': n_windows}
 
 
 def window_owner_ranges(total_frames, world, slice_len=SLICE_MAX, frames=FRAMES):
