@@ -9,16 +9,17 @@
 // at core/process_data.py:272-276 of the reference (rectangular window,
 // nfft 2048, 26 filters, ortho DCT, lifter 22, c0 dropped).
 //
-// FFT decomposition (N = 1024 = 16 x 16 x 4), all index algebra mirrored by
+// FFT decomposition (N = 1024 = 4 x 16 x 16), all index algebra mirrored by
 // tools/fft_lane_model.py:
-//   pass 1  lane n2 holds z[n2 + 64 j]; radix-16 in registers; twiddle W1024^(n2 k1)
-//   xchg 1  through LDS: lane (k1, m2) gathers A[k1][4 m1 + m2]
-//   pass 2  radix-16 in registers; twiddle W64^(m2 q1)
-//   pass 3  radix-4 across the 4 lanes of a quad with DPP quad_perm moves;
-//           lane r of a quad ends with q2 = bitrev2(r)
-//   result  lane (k1, r), register q1 holds Z[k1 + 16 q1 + 256 q2]
-// The real-input untangle needs Z[k] and Z[1024 - k], so Z takes one more trip
-// through LDS; the power spectrum is left in LDS for the mel stage.
+//   pass A  lane L holds z[L + 64 jj]; radix-4 over jj >> 2 in registers; twiddle W1024^(n2 k1)
+//   xchg 1  through LDS: lane (k1, c) gathers the 16 points n2 = c + 16 m of sub-transform k1
+//   pass B  radix-16 over m in registers; twiddle W256^(c q1)
+//   xchg 2  through LDS: lane (k1, q1) gathers the 16 points c
+//   pass C  radix-16 over c in registers
+//   result  lane 16 k1 + q1, register q2 holds Z[k1 + 4 q1 + 64 q2]
+// Z is stored transposed ([q2][lane], a linear image) and the real-input untangle works on the
+// pairs (k, 1024 - k), k < 512, that share Z[k] and Z[1024 - k]; the power spectrum is left in LDS
+// for the mel stage.
 //
 // Precision: FFT, power and mel sums in fp32; filter energies, log and DCT in
 // fp64 (26 logs and 312 fused multiply-adds per frame), because an fp32 log of
@@ -42,12 +43,16 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kFramesPerWave = 4;
 constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
 constexpr int kMaxRun = 20;                   // bins per lane in the mel stage
-constexpr int kExStride = 68;                 // complex elements per k1 row of exchange 1
+constexpr int kEx1Stride = 272;               // exchange 1: complex elements per k1 row (256 + 16: the two
+                                              // k1 rows of a 32-lane half land on opposite bank halves)
+constexpr int kEx2Plane = 273;                // exchange 2: complex elements per k1 plane, 17 per q1 row
+constexpr int kExBytes = 8736;                // >= 4*272*8, >= (3*273 + 15*17 + 16)*8, >= 1024*8
+constexpr int kPowFloats = 1056;              // P[0..1024] plus slack for reads past a lane's run
 
 struct MfccTables {
-    float2 tw1[15][64];      // [k1-1][lane]   W1024^(lane * k1)
-    float2 tw2[15][4];       // [q1-1][m2]     W64^(m2 * q1)
-    float2 twr[16][64];      // [j][lane]      W2048^(lane + 64 j)
+    float2 tw1[12][64];      // [(k1-1)*4 + b][lane]  W1024^((lane + 64 b) * k1)
+    float2 tw2[15][16];      // [q1-1][c]             W256^(c * q1)
+    float2 twr[8][64];       // [jj][lane]            W2048^(k1 + 4 q1 + 64 jj), lane = 16 k1 + q1
     int run_start[64];       // mel stage: first bin of the lane's run
     int run_count[64];       //            bins in the run (0 for idle lanes)
     int run_b0[64];          //            first bin of the run's segment
@@ -110,11 +115,6 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
         }
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float x) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-
 // LDS traffic below is between lanes of ONE wave.  LDS operations of a wave
 // complete in issue order, so only the compiler has to be kept from moving
 // loads above the stores of other lanes.
@@ -126,8 +126,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 constexpr int kStageRows = kFramesPerBlock + 4;              // predecessor row + 16 frames + 3 trailing rows
 constexpr int kStageDwords = kStageRows * (kFrame / 2);       // int16 pairs
-constexpr int kWaveLdsBytes = 16 * kExStride * 8 /*exchange, Z, partial sums, log energies*/ +
-                              1024 * 4 /*power spectrum*/ + kFramesPerWave * 32 * 4 /*filter energies*/;
+constexpr int kWaveLdsBytes = kExBytes /*exchanges, Z, partial sums, log energies*/ +
+                              kPowFloats * 4 /*power spectrum*/ + kFramesPerWave * 32 * 4 /*filter energies*/;
 constexpr int kSmemBytes = kStageDwords * 4 + kNFilt * kNCep * 8 + kWavesPerBlock * kWaveLdsBytes;
 
 // grid: blocks_per_slice blocks for each slice; a block owns 16 consecutive frames of ONE slice, so
@@ -143,12 +143,12 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
     int* stage = reinterpret_cast<int*>(smem);
     double* dct_s = reinterpret_cast<double*>(smem + kStageDwords * 4);
     unsigned char* wbase = smem + kStageDwords * 4 + kNFilt * kNCep * 8 + wave * kWaveLdsBytes;
-    float2* ex = reinterpret_cast<float2*>(wbase);                          // 16 x 68 complex
+    float2* ex = reinterpret_cast<float2*>(wbase);                          // exchange 1 / 2, then Zt[16][64]
     float* part_r = reinterpret_cast<float*>(wbase);                        // aliases ex once Z is consumed
     float* part_f = part_r + 64;
     double* logv = reinterpret_cast<double*>(wbase);                        // aliases ex in the tail
-    float* pw = reinterpret_cast<float*>(wbase + 16 * kExStride * 8);        // 1024 floats
-    float* en = pw + 1024;                                                   // [4 frames][32]
+    float* pw = reinterpret_cast<float*>(wbase + kExBytes);                  // power spectrum
+    float* en = pw + kPowFloats;                                             // [4 frames][32]
 
     const long s = blockIdx.x / blocks_per_slice;
     const int j0 = (int)(blockIdx.x - s * blocks_per_slice) * kFramesPerBlock;
@@ -179,13 +179,13 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
     for (int i = threadIdx.x; i < kNFilt * kNCep; i += 256) dct_s[i] = (&tab->dct[0][0])[i];
 
     // Loop-invariant per-lane constants.
-    float2 tw1[15], tw2[15], twr[16];
+    float2 tw1[12], tw2[15], twr[8];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) tw1[k] = tab->tw1[k][lane];
+    for (int k = 0; k < 12; ++k) tw1[k] = tab->tw1[k][lane];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) tw2[k] = tab->tw2[k][lane & 3];
+    for (int k = 0; k < 15; ++k) tw2[k] = tab->tw2[k][lane & 15];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) twr[j] = tab->twr[j][lane];
+    for (int j = 0; j < 8; ++j) twr[j] = tab->twr[j][lane];
     const int run_start = tab->run_start[lane];
     const int run_count = tab->run_count[lane];
     const float run_b0 = (float)tab->run_b0[lane];
@@ -195,13 +195,13 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
     const int rise_first = tab->rise_first[fl], rise_n = tab->rise_n[fl];
     const int fall_first = tab->fall_first[fl], fall_n = tab->fall_n[fl];
 
-    const int r4 = lane & 3;
-    const float sA = (r4 & 2) ? -1.0f : 1.0f;
-    const float cx = (r4 & 1) ? -1.0f : 1.0f;              // r: 0 -> +, 1 -> -, 2 -> +, 3 -> -
-    const float cy = (r4 == 0 || r4 == 3) ? 1.0f : -1.0f;  // r: 0 -> +, 1 -> -, 2 -> -, 3 -> +
-    const bool is2 = (r4 == 2);
-    const bool swp = (r4 >= 2);
-    const int q2 = ((r4 & 1) << 1) | (r4 >> 1);
+    const float run_w0 = ((float)run_start - run_b0) * run_inv;      // rising weight of the run's first bin
+    const float run_f0 = (run_b1 - (float)run_start) * run_inv;      // falling weight of the run's first bin
+    // untangle partner of bin k = k1 + 4 q1 + 64 jj: Zt[(15 - jj + pd) & 15][plane]
+    const int k1l = lane >> 4, q1l = lane & 15;
+    const int plane = k1l ? 16 * (4 - k1l) + 15 - q1l : (q1l ? 16 - q1l : 0);
+    const int pd = (lane == 0) ? 1 : 0;
+    const int kbase = k1l + 4 * q1l;
 
     __syncthreads();
 
@@ -230,61 +230,69 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
             v[15] = make_float2(0.0f, 0.0f);                // samples 1920..2047 are zero padding
         }
 
-        // ---- pass 1 ----
-        dft16(v);
+        // ---- pass A: radix 4 over n1 = jj >> 2; outputs k1 land in v[4 k1 + b] ----
 #pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw1[k - 1]);
+        for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[4 + k] = cmul(v[4 + k], tw1[k]);
 
-        // ---- exchange 1: [k1][n2] -> lane (k1, m2) reads n2 = 4 m1 + m2 ----
+        // ---- exchange 1: [k1][n2 = lane + 64 b] -> lane (k1, c) reads n2 = c + 16 m ----
 #pragma unroll
-        for (int k = 0; k < 16; ++k) ex[k * kExStride + lane] = v[k];
+        for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) ex[k1 * kEx1Stride + lane + 64 * b] = v[4 * k1 + b];
         wave_lds_fence();
         {
-            const float2* rd = ex + (lane >> 2) * kExStride + (lane & 3);
+            const float2* rd = ex + k1l * kEx1Stride + q1l;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = rd[4 * m];
+            for (int m = 0; m < 16; ++m) v[m] = rd[16 * m];
         }
         wave_lds_fence();
 
-        // ---- pass 2 ----
+        // ---- pass B: radix 16 over m; twiddle W256^(c q1) ----
         dft16(v);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw2[k - 1]);
 
-        // ---- pass 3: radix-4 across the quad ----
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float2 p = make_float2(dpp_quad<0x4E>(v[k].x), dpp_quad<0x4E>(v[k].y));      // lane ^ 2
-            const float2 t = make_float2(fmaf(sA, v[k].x, p.x), fmaf(sA, v[k].y, p.y));
-            p = make_float2(dpp_quad<0xB1>(t.x), dpp_quad<0xB1>(t.y));                    // lane ^ 1
-            const float2 u = is2 ? t : p;
-            const float2 w = is2 ? p : t;
-            const float wx = swp ? w.y : w.x;
-            const float wy = swp ? w.x : w.y;
-            v[k] = make_float2(fmaf(cx, wx, u.x), fmaf(cy, wy, u.y));
-        }
-
-        // ---- Z[k] to LDS at k + 4 (k >> 8), k = k1 + 16 q1 + 256 q2 ----
+        // ---- exchange 2: [k1][q1][c] -> lane (k1, q1) reads c = 0..15 ----
         {
-            float2* wr = ex + (lane >> 2) + 260 * q2;
+            float2* wr = ex + k1l * kEx2Plane + q1l;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) wr[16 * k] = v[k];
+            for (int q = 0; q < 16; ++q) wr[17 * q] = v[q];
+        }
+        wave_lds_fence();
+        {
+            const float2* rd = ex + k1l * kEx2Plane + 17 * q1l;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = rd[c];
         }
         wave_lds_fence();
 
-        // ---- real-input untangle and power spectrum for bins k = lane + 64 jj ----
+        // ---- pass C: radix 16 over c; register q2 now holds Z[k1 + 4 q1 + 64 q2] ----
+        dft16(v);
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int k = lane + 64 * jj;
-            const int kk = (1024 - k) & 1023;
-            const float2 a = ex[k + 4 * (jj >> 2)];
-            const float2 b = ex[kk + 4 * (kk >> 8)];
-            const float2 e = make_float2(a.x + b.x, a.y - b.y);          // Z[k] + conj(Z[N-k])
-            const float2 o = make_float2(a.x - b.x, a.y + b.y);          // Z[k] - conj(Z[N-k])
-            const float2 wo = cmul(twr[jj], o);
-            const float xr = e.x + wo.y;                                  // 2 Re X[k]
-            const float xi = e.y - wo.x;                                  // 2 Im X[k]
-            pw[k] = (xr * xr + xi * xi) * (0.25f / 2048.0f);
+        for (int q = 0; q < 16; ++q) ex[64 * q + lane] = v[q];             // Zt[q2][lane]
+        wave_lds_fence();
+
+        // ---- real-input untangle on the pairs (k, 1024 - k), k = k1 + 4 q1 + 64 jj < 512:
+        //      with E = Z[k] + conj(Z[N-k]), O = Z[k] - conj(Z[N-k]), T = W2048^k O,
+        //      4 |X[k]|^2 = |E - iT|^2 and 4 |X[N-k]|^2 = |E + iT|^2 ----
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float2 a = ex[64 * jj + lane];
+            const float2 b = ex[64 * ((15 - jj + pd) & 15) + plane];
+            const float2 e = make_float2(a.x + b.x, a.y - b.y);
+            const float2 o = make_float2(a.x - b.x, a.y + b.y);
+            const float2 t = cmul(twr[jj], o);
+            const float ar = e.x + t.y, ai = e.y - t.x;                   // E - iT
+            const float br = e.x - t.y, bi = e.y + t.x;                   // E + iT
+            const int k = kbase + 64 * jj;
+            pw[k] = (ar * ar + ai * ai) * (0.25f / 2048.0f);
+            pw[1024 - k] = (br * br + bi * bi) * (0.25f / 2048.0f);
+        }
+        if (lane == 0) {                                                  // the self-paired bin 512
+            const float2 a = ex[64 * 8];
+            pw[512] = (a.x * a.x + a.y * a.y) * (1.0f / 2048.0f);
         }
         wave_lds_fence();
 
@@ -292,13 +300,12 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
         // 20 reads issue back to back, lanes past their run add zeros) ----
         {
             float sr = 0.0f, sf = 0.0f;
+            const float* run = pw + run_start;
 #pragma unroll
             for (int i = 0; i < kMaxRun; ++i) {
-                const int bin = min(run_start + i, 1023);
-                const float p = (i < run_count) ? pw[bin] : 0.0f;
-                const float fb = (float)bin;
-                sr = fmaf(p, (fb - run_b0) * run_inv, sr);
-                sf = fmaf(p, (run_b1 - fb) * run_inv, sf);
+                const float p = (i < run_count) ? run[i] : 0.0f;
+                sr = fmaf(p, fmaf((float)i, run_inv, run_w0), sr);
+                sf = fmaf(p, fmaf(-(float)i, run_inv, run_f0), sf);
             }
             part_r[lane] = sr;                                            // ex is free again (Z consumed)
             part_f[lane] = sf;
@@ -368,19 +375,20 @@ double mel2hz(double mel) { return 700.0 * (pow(10.0, mel / 2595.0) - 1.0); }
 void build_tables(MfccTables& t) {
     memset(&t, 0, sizeof(t));
     const double pi = 3.14159265358979323846;
-    for (int k1 = 1; k1 < 16; ++k1)
-        for (int l = 0; l < 64; ++l) {
-            const double a = -2.0 * pi * (double)(l * k1) / 1024.0;
-            t.tw1[k1 - 1][l] = make_float2((float)cos(a), (float)sin(a));
-        }
+    for (int k1 = 1; k1 < 4; ++k1)
+        for (int b = 0; b < 4; ++b)
+            for (int l = 0; l < 64; ++l) {
+                const double a = -2.0 * pi * (double)((l + 64 * b) * k1) / 1024.0;
+                t.tw1[(k1 - 1) * 4 + b][l] = make_float2((float)cos(a), (float)sin(a));
+            }
     for (int q1 = 1; q1 < 16; ++q1)
-        for (int m2 = 0; m2 < 4; ++m2) {
-            const double a = -2.0 * pi * (double)(m2 * q1) / 64.0;
-            t.tw2[q1 - 1][m2] = make_float2((float)cos(a), (float)sin(a));
+        for (int c = 0; c < 16; ++c) {
+            const double a = -2.0 * pi * (double)(c * q1) / 256.0;
+            t.tw2[q1 - 1][c] = make_float2((float)cos(a), (float)sin(a));
         }
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < 8; ++j)
         for (int l = 0; l < 64; ++l) {
-            const double a = -2.0 * pi * (double)(l + 64 * j) / 2048.0;
+            const double a = -2.0 * pi * (double)((l >> 4) + 4 * (l & 15) + 64 * j) / 2048.0;
             t.twr[j][l] = make_float2((float)cos(a), (float)sin(a));
         }
 
