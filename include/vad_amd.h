@@ -104,7 +104,8 @@ int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, int64_t fram
  * (G*H,H), rnn.bias_ih_l0, rnn.bias_hh_l0 (G*H) with G = 3 (GRU: r,z,n) or
  * 4 (LSTM: i,f,g,o); lin1 (26, 30*H) + (26); lin2 (2,26) + (2); lin (2, 30*H)
  * + (2).  `large` selects lin1/lin2, otherwise lin; the unused head may be
- * NULL.  hidden = 30 is the reference architecture; 1..32 is accepted.
+ * NULL.  hidden = 30 is the reference architecture; 1..32 is accepted for the
+ * LSTM and 1..96 for the GRU (the enlarged-GRU configuration uses 90).
  */
 size_t vad_net_blob_floats(int lstm, int large, int hidden);
 int vad_pack_net_weights(int lstm, int large, int hidden,

@@ -108,6 +108,35 @@ def test_threshold_decisions(vad, kind):
         _decisions_agree(got, y, threshold=t)
 
 
+@pytest.mark.parametrize('hidden,large', [(90, True), (90, False), (64, True), (33, False), (17, True)])
+def test_gru_other_hidden_sizes(vad, hidden, large):
+    """Enlarged GRU (hidden 90, ~100k parameters): no class in the reference, oracle = torch.nn.GRU + Linear."""
+    ref = models_ref.make_model('gru_large' if large else 'gru_small', hidden=hidden)
+    net = vad.Net(large=large, lstm=False, hidden=hidden)
+    net.load_state_dict(ref.state_dict())
+    if hidden == 90 and large:
+        assert sum(p.numel() for p in ref.rnn.parameters()) + sum(p.numel() for p in ref.lin1.parameters()) \
+            + sum(p.numel() for p in ref.lin2.parameters()) == 101600
+    x = torch.randn(300, 30, 24, generator=torch.Generator().manual_seed(hidden)) * 4.0
+    with torch.no_grad():
+        y = ref(x).numpy()
+    p, dec = net.score(x.cuda())
+    assert np.abs(p.cpu().numpy() - y).max() <= ATOL
+    _decisions_agree(dec.cpu().numpy(), y)
+    # stride-1 windows over a feature matrix take the same path for wide models
+    feat = torch.randn(200, 24, generator=torch.Generator().manual_seed(1)) * 3.0
+    xw = torch.from_numpy(pipeline_ref.windows(feat.numpy()))
+    ps, _ = net.score(feat.cuda(), window_stride=24)
+    pb, _ = net.score(xw.cuda())
+    assert torch.equal(ps, pb)
+
+
+def test_lstm_wide_hidden_is_rejected(vad):
+    net = vad.Net(large=False, lstm=True, hidden=64)
+    with pytest.raises(vad.VadError):
+        net(torch.zeros(4, 30, 24))
+
+
 def test_weight_updates_are_picked_up(vad):
     net = vad.Net(large=True, lstm=False)
     x = torch.randn(64, 30, 24, generator=torch.Generator().manual_seed(1)).cuda()

@@ -65,7 +65,11 @@ extern "C" int vad_abi_version(void) { return 1; }
 
 extern "C" const char* vad_last_error(void) { return vad::g_err; }
 
-extern "C" int vad_init(void) { return vad::ensure_mfcc_tables(); }
+extern "C" int vad_init(void) {
+    int rc = vad::ensure_mfcc_tables();
+    if (rc != VAD_OK) return rc;
+    return vad::ensure_rnn_attrs();
+}
 
 extern "C" int vad_synth_audio_i16(int16_t* out_dev, int64_t first_sample, int64_t n_samples, uint32_t seed,
                                    void* stream) {

@@ -55,28 +55,33 @@ constexpr int kWavesPerBlock = 4;   // rnn_kernel
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Blob layout in floats; shared by the host packer and the kernels.
+// Blob layout in floats; shared by the host packer and the kernels.  `ut` = number of 32-unit
+// tiles covering the hidden size (1 for the reference's H = 30, 3 for H = 90).
 struct NetLayout {
     int gates;        // 3 GRU, 4 LSTM
-    int a_ih;         // [gates][12][64]   A operands of the input projection
-    int a_hh;         // [gates][16][64]   A operands of the recurrent product
-    int cb;           // [4][2][16]        accumulator initial values (biases), per lane half
-    int head;         // a1 [30][16][64]   A operands of lin1 (large) or lin (small, rows 0-1)
+    int ut;
+    int a_ih;         // [gates][ut][12][64]        A operands of the input projection
+    int a_hh;         // [gates][ut][ut*16][64]     A operands of the recurrent product
+    int cb;           // [4][ut][2][16]             accumulator initial values (biases), per lane half
+    int head;         // a1 [30][ut*16][64]         A operands of lin1 (large) or lin (small, rows 0-1)
     int tail;         // large: b1e [2][16], w2e [2][2][16], b2 [2] (+2 pad); small: bl [2] (+2 pad)
     int total;
 };
 
-__host__ __device__ inline NetLayout net_layout(bool lstm, bool large) {
+__host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 1) {
     NetLayout L;
     L.gates = lstm ? 4 : 3;
+    L.ut = ut;
     L.a_ih = 0;
-    L.a_hh = L.a_ih + L.gates * kKs * 64;
-    L.cb = L.a_hh + L.gates * kHk * 64;
-    L.head = L.cb + 4 * 2 * 16;
-    L.tail = L.head + kT * kHk * 64;
+    L.a_hh = L.a_ih + L.gates * ut * kKs * 64;
+    L.cb = L.a_hh + L.gates * ut * ut * kHk * 64;
+    L.head = L.cb + 4 * ut * 2 * 16;
+    L.tail = L.head + kT * ut * kHk * 64;
     L.total = L.tail + (large ? (2 * 16 + 2 * 2 * 16 + 4) : 4);
     return L;
 }
+
+__host__ __device__ inline int unit_tiles(int hidden) { return (hidden + 31) / 32; }
 
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -323,6 +328,137 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
 }
 
 // ---------------------------------------------------------------------------------------------
+// GRU with 33..96 hidden units (UT = 2 or 3 unit tiles), any window stride.  Same cell as rnn_kernel,
+// one 32-unit tile of the new state at a time: the accumulators of a tile (r, z, n-input, n-hidden)
+// see the whole previous state as B operand, so the new state is double-buffered in registers.
+
+template <bool LARGE, int UT>
+__global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restrict__ x, long n_windows, long wstride,
+                                                          const float* __restrict__ blob, float* __restrict__ p_out,
+                                                          uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    extern __shared__ __align__(16) float lds[];
+    const NetLayout L = net_layout(false, LARGE, UT);
+    for (int i = threadIdx.x; i < L.head; i += blockDim.x) lds[i] = blob[i];
+    __syncthreads();
+    const float* a_ih = lds + L.a_ih;
+    const float* a_hh = lds + L.a_hh;
+    const float* cb = lds + L.cb;
+    const float* a1 = blob + L.head;
+
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const long tile = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long w = tile * kWindowsPerWave + col;
+    if (tile * kWindowsPerWave >= n_windows) return;
+    const long wc = w < n_windows ? w : n_windows - 1;
+    const float* xw = x + wc * wstride + 12 * half;
+
+    f32x16 h[UT], hn[UT], lacc;
+#pragma unroll
+    for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[u][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.0f;
+
+    for (int t = 0; t < kT; ++t) {
+        const float4 xa = *reinterpret_cast<const float4*>(xw + t * kF);
+        const float4 xb = *reinterpret_cast<const float4*>(xw + t * kF + 4);
+        const float4 xc = *reinterpret_cast<const float4*>(xw + t * kF + 8);
+        const float xv[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+#pragma unroll
+        for (int mt = 0; mt < UT; ++mt) {
+            __builtin_amdgcn_sched_barrier(0);           // keep the A-operand reads of later tiles from piling up
+            f32x16 acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = load16(cb + ((a * UT + mt) * 2 + half) * 16);
+#pragma unroll
+            for (int sft = 0; sft < kKs; ++sft)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = MFMA(a_ih[((g * UT + mt) * kKs + sft) * 64 + lane], xv[sft], acc[g]);
+            if (t > 0) {
+#pragma unroll
+                for (int kt = 0; kt < UT; ++kt) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < kHk; ++i) {
+                        const float hv = h[kt][i];
+                        const int ks = kt * kHk + i;
+                        acc[0] = MFMA(a_hh[((0 * UT + mt) * UT * kHk + ks) * 64 + lane], hv, acc[0]);
+                        acc[1] = MFMA(a_hh[((1 * UT + mt) * UT * kHk + ks) * 64 + lane], hv, acc[1]);
+                        acc[3] = MFMA(a_hh[((2 * UT + mt) * UT * kHk + ks) * 64 + lane], hv, acc[3]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float r = fast_sigmoid(acc[0][i]);
+                const float z = fast_sigmoid(acc[1][i]);
+                const float n = fast_tanh(fmaf(r, acc[3][i], acc[2][i]));
+                hn[mt][i] = fmaf(z, h[mt][i] - n, n);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) h[u] = hn[u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < UT; ++kt)
+#pragma unroll
+            for (int i = 0; i < kHk; ++i) lacc = MFMA(a1[(t * UT * kHk + kt * kHk + i) * 64 + lane], h[kt][i], lacc);
+    }
+    head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
+}
+
+template <typename K>
+int allow_lds(K kernel, int floats) {
+    VAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      floats * (int)sizeof(float)));
+    return VAD_OK;
+}
+
+}  // namespace
+
+// Kernels that use more than 64 KB of dynamic LDS must be opted in once per device.
+int ensure_rnn_attrs() {
+    static bool done[64] = {false};
+    int dev = 0;
+    VAD_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return VAD_OK;
+    if (done[dev]) return VAD_OK;
+    int rc = VAD_OK;
+    if ((rc = allow_lds(&rnn_stream_kernel<false, false>, StreamCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<false, true>, StreamCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<true, false>, StreamCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<true, true>, StreamCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&gru_wide_kernel<false, 2>, net_layout(false, false, 2).head))) return rc;
+    if ((rc = allow_lds(&gru_wide_kernel<true, 2>, net_layout(false, true, 2).head))) return rc;
+    if ((rc = allow_lds(&gru_wide_kernel<false, 3>, net_layout(false, false, 3).head))) return rc;
+    if ((rc = allow_lds(&gru_wide_kernel<true, 3>, net_layout(false, true, 3).head))) return rc;
+    done[dev] = true;
+    return VAD_OK;
+}
+
+namespace {
+
+template <bool LARGE, int UT>
+int launch_wide(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
+                float threshold, hipStream_t st) {
+    const NetLayout L = net_layout(false, LARGE, UT);
+    const size_t lds_bytes = (size_t)L.head * sizeof(float);
+    int rc = ensure_rnn_attrs();
+    if (rc != VAD_OK) return rc;
+    const long per_block = (long)kWindowsPerWave * kWavesPerBlock;
+    const long blocks = (n_windows + per_block - 1) / per_block;
+    VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
+    hipLaunchKernelGGL((gru_wide_kernel<LARGE, UT>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds_bytes, st, x,
+                       n_windows, wstride, blob, p, dec, mode, threshold);
+    VAD_HIP_CHECK(hipGetLastError());
+    return VAD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 
 template <bool LSTM, bool LARGE>
@@ -330,15 +466,9 @@ int launch(const float* x, long n_windows, long wstride, const float* blob, floa
            float threshold, hipStream_t st) {
     if (wstride == kF) {
         using C = StreamCfg<LSTM>;
-        static bool attr_set[64] = {false};                      // per device; >64 KB of dynamic LDS needs opting in
-        int dev = 0;
-        VAD_HIP_CHECK(hipGetDevice(&dev));
+        int rc = ensure_rnn_attrs();
+        if (rc != VAD_OK) return rc;
         const size_t lds_bytes = (size_t)C::lds_floats * sizeof(float);
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-            VAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_stream_kernel<LSTM, LARGE>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            attr_set[dev] = true;
-        }
         const long blocks = (n_windows + C::windows - 1) / C::windows;
         VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
         hipLaunchKernelGGL((rnn_stream_kernel<LSTM, LARGE>), dim3((unsigned)blocks), dim3(C::waves * 64), lds_bytes, st, x,
@@ -360,7 +490,8 @@ int launch(const float* x, long n_windows, long wstride, const float* blob, floa
 int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const float* blob, int hidden, int large,
             float* p, uint8_t* dec, int mode, float threshold, void* stream) {
     VAD_REQUIRE(x && blob && p, "null pointer argument");
-    VAD_REQUIRE(hidden >= 1 && hidden <= kHp, "hidden must be in 1..32 (got %d)", hidden);
+    VAD_REQUIRE(hidden >= 1 && hidden <= (lstm ? kHp : 3 * kHp),
+                "hidden must be in 1..32 (LSTM) or 1..96 (GRU), got %d", hidden);
     VAD_REQUIRE(n_windows >= 0, "n_windows must be >= 0");
     VAD_REQUIRE(wstride >= 0 && (wstride % 4) == 0, "window_stride must be a non-negative multiple of 4 floats");
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x_dev must be 16-byte aligned");
@@ -373,6 +504,12 @@ int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const
         return large ? launch<true, true>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
                      : launch<true, false>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
     }
+    if (hidden > 2 * kHp)
+        return large ? launch_wide<true, 3>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
+                     : launch_wide<false, 3>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
+    if (hidden > kHp)
+        return large ? launch_wide<true, 2>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
+                     : launch_wide<false, 2>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
     return large ? launch<false, true>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
                  : launch<false, false>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
 }
@@ -382,8 +519,8 @@ int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const
 }  // namespace vad
 
 extern "C" size_t vad_net_blob_floats(int lstm, int large, int hidden) {
-    (void)hidden;
-    return (size_t)vad::net_layout(lstm != 0, large != 0).total;
+    if (hidden < 1 || hidden > (lstm ? vad::kHp : 3 * vad::kHp)) return 0;
+    return (size_t)vad::net_layout(lstm != 0, large != 0, vad::unit_tiles(hidden)).total;
 }
 
 extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float* w_ih, const float* w_hh,
@@ -392,46 +529,52 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
                                     float* blob, size_t blob_floats) {
     using namespace vad;
     VAD_REQUIRE(w_ih && w_hh && b_ih && b_hh && blob, "null pointer argument");
-    VAD_REQUIRE(hidden >= 1 && hidden <= kHp, "hidden must be in 1..32 (got %d)", hidden);
+    VAD_REQUIRE(hidden >= 1 && hidden <= (lstm ? kHp : 3 * kHp),
+                "hidden must be in 1..32 (LSTM) or 1..96 (GRU), got %d", hidden);
     if (large) VAD_REQUIRE(lin1_w && lin1_b && lin2_w && lin2_b, "large head needs lin1 and lin2");
     else VAD_REQUIRE(lin_w && lin_b, "small head needs lin");
-    const NetLayout L = net_layout(lstm != 0, large != 0);
+    const int UT = unit_tiles(hidden);
+    const NetLayout L = net_layout(lstm != 0, large != 0, UT);
     VAD_REQUIRE(blob_floats >= (size_t)L.total, "blob too small: need %d floats", L.total);
-    const int H = hidden, G = L.gates;
+    const int H = hidden, G = L.gates, KH = UT * kHk;
     memset(blob, 0, sizeof(float) * (size_t)L.total);
     for (int g = 0; g < G; ++g)
-        for (int lane = 0; lane < 64; ++lane) {
-            const int m = lane & 31, hh = lane >> 5;
-            if (m >= H) continue;
-            for (int s = 0; s < kKs; ++s) blob[L.a_ih + (g * kKs + s) * 64 + lane] = w_ih[(g * H + m) * kF + s + 12 * hh];
-            for (int i = 0; i < kHk; ++i) {
-                const int u = mfma32_row(i, hh);
-                if (u < H) blob[L.a_hh + (g * kHk + i) * 64 + lane] = w_hh[(g * H + m) * H + u];
+        for (int mt = 0; mt < UT; ++mt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = 32 * mt + (lane & 31), hh = lane >> 5;
+                if (m >= H) continue;
+                for (int s = 0; s < kKs; ++s)
+                    blob[L.a_ih + ((g * UT + mt) * kKs + s) * 64 + lane] = w_ih[(g * H + m) * kF + s + 12 * hh];
+                for (int ks = 0; ks < KH; ++ks) {
+                    const int u = 32 * (ks / kHk) + mfma32_row(ks % kHk, hh);
+                    if (u < H) blob[L.a_hh + ((g * UT + mt) * KH + ks) * 64 + lane] = w_hh[(g * H + m) * H + u];
+                }
             }
-        }
-    for (int hh = 0; hh < 2; ++hh)
-        for (int i = 0; i < 16; ++i) {
-            const int u = mfma32_row(i, hh);
-            if (u >= H) continue;
-            float* cb = blob + L.cb;
-            if (lstm) {
-                for (int g = 0; g < 4; ++g) cb[(g * 2 + hh) * 16 + i] = b_ih[g * H + u] + b_hh[g * H + u];
-            } else {
-                cb[(0 * 2 + hh) * 16 + i] = b_ih[u] + b_hh[u];                    // r
-                cb[(1 * 2 + hh) * 16 + i] = b_ih[H + u] + b_hh[H + u];            // z
-                cb[(2 * 2 + hh) * 16 + i] = b_ih[2 * H + u];                      // W_in x + b_in
-                cb[(3 * 2 + hh) * 16 + i] = b_hh[2 * H + u];                      // W_hn h + b_hn
+    for (int mt = 0; mt < UT; ++mt)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int i = 0; i < 16; ++i) {
+                const int u = 32 * mt + mfma32_row(i, hh);
+                if (u >= H) continue;
+                float* cb = blob + L.cb;
+                auto at = [&](int a) -> float& { return cb[((a * UT + mt) * 2 + hh) * 16 + i]; };
+                if (lstm) {
+                    for (int g = 0; g < 4; ++g) at(g) = b_ih[g * H + u] + b_hh[g * H + u];
+                } else {
+                    at(0) = b_ih[u] + b_hh[u];                    // r
+                    at(1) = b_ih[H + u] + b_hh[H + u];            // z
+                    at(2) = b_ih[2 * H + u];                      // W_in x + b_in
+                    at(3) = b_hh[2 * H + u];                      // W_hn h + b_hn
+                }
             }
-        }
-    // head: rows of lin1 (26) or lin (2) as one 32-row A tile per step
+    // head: rows of lin1 (26) or lin (2) as one 32-row A tile per k-step
     const float* hw = large ? lin1_w : lin_w;
     const int rows = large ? kL1 : 2;
     float* head = blob + L.head;
     for (int t = 0; t < kT; ++t)
-        for (int i = 0; i < kHk; ++i)
+        for (int ks = 0; ks < KH; ++ks)
             for (int lane = 0; lane < 64; ++lane) {
-                const int o = lane & 31, u = mfma32_row(i, lane >> 5);
-                if (o < rows && u < H) head[(t * kHk + i) * 64 + lane] = hw[o * (kT * H) + t * H + u];
+                const int o = lane & 31, u = 32 * (ks / kHk) + mfma32_row(ks % kHk, lane >> 5);
+                if (o < rows && u < H) head[(t * KH + ks) * 64 + lane] = hw[o * (kT * H) + t * H + u];
             }
     float* tail = blob + L.tail;
     if (large) {

@@ -33,6 +33,9 @@ void set_error(const char* fmt, ...);
 // Per-device constant tables of the MFCC front end; defined in mfcc.hip.
 int ensure_mfcc_tables();
 
+// One-time per-device opt-in of the model kernels that need more than 64 KB of LDS; defined in rnn.hip.
+int ensure_rnn_attrs();
+
 // 32x32 MFMA accumulator geometry (v_mfma_f32_32x32x2_f32): register i of a
 // lane in half hh (= lane >> 5) holds row (i & 3) + 8 * (i >> 2) + 4 * hh of
 // the 32-row tile; the column is lane & 31.

@@ -105,22 +105,26 @@ class _HipModule(nn.Module):
 class Net(_HipModule):
     """core/models.py:9-81: 1-layer LSTM or GRU (24 -> 30), flatten, lin1+ReLU+lin2 or lin, softmax."""
 
-    def __init__(self, large=True, lstm=True):
+    def __init__(self, large=True, lstm=True, hidden=FRAMES):
+        # ``hidden`` is an extension: the reference hard-wires FRAMES = 30 (core/models.py:19-25); the
+        # enlarged-GRU benchmark configuration uses 90.
         super().__init__()
         self.large = large
         self.lstm = lstm
         self.relu = nn.ReLU()
         cls = nn.LSTM if lstm else nn.GRU
-        self.rnn = cls(input_size=FEATURES, hidden_size=FRAMES, num_layers=1, batch_first=True)
-        self.lin1 = nn.Linear(FRAMES ** 2, 26)
+        self.rnn = cls(input_size=FEATURES, hidden_size=hidden, num_layers=1, batch_first=True)
+        self.lin1 = nn.Linear(FRAMES * hidden, 26)
         self.lin2 = nn.Linear(26, 2)
-        self.lin = nn.Linear(FRAMES ** 2, 2)
+        self.lin = nn.Linear(FRAMES * hidden, 2)
         self.softmax = nn.Softmax(dim=1)
 
     def _pack(self):
         L = _lib.lib()
         H = self.rnn.hidden_size
         n = L.vad_net_blob_floats(int(self.lstm), int(self.large), H)
+        if n == 0:
+            raise _lib.VadError('hidden size %d is not supported (LSTM 1..32, GRU 1..96)' % H)
         blob = np.zeros(n, np.float32)
         a = {k: _np32(v) for k, v in self.state_dict().items()}
         hp = _lib.host_ptr
