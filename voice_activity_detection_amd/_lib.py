@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'libvad_amd.so')
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip']
+HEADERS = ['vad_internal.h', 'mfcc_device.h', 'rnn_device.h']
 
 # every symbol include/vad_amd.h declares
 SYMBOLS = [
@@ -35,7 +36,7 @@ _lib = None
 def build(verbose=False):
     """Compile the HIP sources for gfx950 into the in-tree shared library."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'vad_internal.h'), os.path.join(INCLUDE, 'vad_amd.h')]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, 'vad_amd.h')]
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

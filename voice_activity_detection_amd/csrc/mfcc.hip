@@ -30,104 +30,18 @@
 #include <mutex>
 #include <vector>
 
-#include "vad_internal.h"
+#include "mfcc_device.h"
 
 namespace vad {
 
+using namespace fe;
+
 namespace {
 
-constexpr int kFrame = VAD_FRAME_SIZE;        // 480
-constexpr int kNFilt = 26;
-constexpr int kNCep = VAD_NUM_CEPS;           // 12
 constexpr int kWavesPerBlock = 4;
-constexpr int kFramesPerWave = 4;
 constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
-constexpr int kMaxRun = 20;                   // bins per lane in the mel stage
-constexpr int kEx1Stride = 272;               // exchange 1: complex elements per k1 row (256 + 16: the two
-                                              // k1 rows of a 32-lane half land on opposite bank halves)
-constexpr int kEx2Plane = 273;                // exchange 2: complex elements per k1 plane, 17 per q1 row
-constexpr int kExBytes = 8736;                // >= 4*272*8, >= (3*273 + 15*17 + 16)*8, >= 1024*8
-constexpr int kPowFloats = 1056;              // P[0..1024] plus slack for reads past a lane's run
-
-struct MfccTables {
-    float2 tw1[12][64];      // [(k1-1)*4 + b][lane]  W1024^((lane + 64 b) * k1)
-    float2 tw2[15][16];      // [q1-1][c]             W256^(c * q1)
-    float2 twr[8][64];       // [jj][lane]            W2048^(k1 + 4 q1 + 64 jj), lane = 16 k1 + q1
-    int run_start[64];       // mel stage: first bin of the lane's run
-    int run_count[64];       //            bins in the run (0 for idle lanes)
-    int run_b0[64];          //            first bin of the run's segment
-    int run_b1[64];          //            one past the last bin of the segment
-    float run_inv[64];       //            1 / (b1 - b0)
-    int rise_first[kNFilt];  // filter f = rising parts of lanes [rise_first, +rise_n)
-    int rise_n[kNFilt];
-    int fall_first[kNFilt];  //          + falling parts of lanes [fall_first, +fall_n)
-    int fall_n[kNFilt];
-    double dct[kNFilt][kNCep];   // sqrt(2/26) * lifter(k) * cos(pi k (2n+1) / 52), k = 1..12
-};
-
-// ---------------------------------------------------------------------------------------------
-// device helpers
-
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
-}
-
-// Forward 4-point DFT in place (W4 = -i).
-__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
-    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3);
-    const float2 d = csub(a1, a3);
-    const float2 t3 = make_float2(d.y, -d.x);          // (a1 - a3) * (-i)
-    a0 = cadd(t0, t2);
-    a1 = cadd(t1, t3);
-    a2 = csub(t0, t2);
-    a3 = csub(t1, t3);
-}
-
-// Forward 16-point DFT in place, natural order in and out.
-__device__ __forceinline__ void dft16(float2 (&v)[16]) {
-    constexpr float C1 = 0.92387953251128673848f;      // cos(pi/8)
-    constexpr float S1 = 0.38268343236508978178f;      // sin(pi/8)
-    constexpr float R2 = 0.70710678118654752440f;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
-    // v[4c + b] *= W16^(b c)
-    v[5] = cmul(v[5], make_float2(C1, -S1));           // b=1 c=1
-    v[9] = cmul(v[9], make_float2(R2, -R2));           // b=1 c=2
-    v[13] = cmul(v[13], make_float2(S1, -C1));         // b=1 c=3
-    v[6] = cmul(v[6], make_float2(R2, -R2));           // b=2 c=1
-    v[10] = make_float2(v[10].y, -v[10].x);            // b=2 c=2  (-i)
-    v[14] = cmul(v[14], make_float2(-R2, -R2));        // b=2 c=3
-    v[7] = cmul(v[7], make_float2(S1, -C1));           // b=3 c=1
-    v[11] = cmul(v[11], make_float2(-R2, -R2));        // b=3 c=2
-    v[15] = cmul(v[15], make_float2(-C1, S1));         // b=3 c=3  W16^9
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
-    // X[c + 4 d] sits at v[4 c + d]: transpose the 4x4 register block.
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int d = c + 1; d < 4; ++d) {
-            const float2 t = v[4 * c + d];
-            v[4 * c + d] = v[4 * d + c];
-            v[4 * d + c] = t;
-        }
-}
-
-// LDS traffic below is between lanes of ONE wave.  LDS operations of a wave
-// complete in issue order, so only the compiler has to be kept from moving
-// loads above the stores of other lanes.
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 constexpr int kStageRows = kFramesPerBlock + 4;              // predecessor row + 16 frames + 3 trailing rows
 constexpr int kStageDwords = kStageRows * (kFrame / 2);       // int16 pairs
-constexpr int kWaveLdsBytes = kExBytes /*exchanges, Z, partial sums, log energies*/ +
-                              kPowFloats * 4 /*power spectrum*/ + kFramesPerWave * 32 * 4 /*filter energies*/;
 constexpr int kSmemBytes = kStageDwords * 4 + kNFilt * kNCep * 8 + kWavesPerBlock * kWaveLdsBytes;
 
 // grid: blocks_per_slice blocks for each slice; a block owns 16 consecutive frames of ONE slice, so
@@ -144,9 +58,6 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
     double* dct_s = reinterpret_cast<double*>(smem + kStageDwords * 4);
     unsigned char* wbase = smem + kStageDwords * 4 + kNFilt * kNCep * 8 + wave * kWaveLdsBytes;
     float2* ex = reinterpret_cast<float2*>(wbase);                          // exchange 1 / 2, then Zt[16][64]
-    float* part_r = reinterpret_cast<float*>(wbase);                        // aliases ex once Z is consumed
-    float* part_f = part_r + 64;
-    double* logv = reinterpret_cast<double*>(wbase);                        // aliases ex in the tail
     float* pw = reinterpret_cast<float*>(wbase + kExBytes);                  // power spectrum
     float* en = pw + kPowFloats;                                             // [4 frames][32]
 
@@ -155,7 +66,9 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
     const long n_s = (s == n_slices - 1) ? last_slice_frames : frames_per_slice;
     if (j0 >= n_s) return;                                                   // block-uniform
 
-    // ---- stage aligned rows j0-1 .. j0+18 of the slice (zeros outside it) ----
+    // ---- stage aligned rows j0-1 .. j0+18 of the slice (zeros outside it).  The row in front of a
+    // slice's first aligned row is staged as zeros, which leaves that row un-emphasised exactly as
+    // the reference's 2-D preemphasis does. ----
     {
         const int16_t* slice = in + s * slice_stride;
         const long rows = n_s + VAD_ALIGN_FRAMES;
@@ -178,31 +91,8 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
     }
     for (int i = threadIdx.x; i < kNFilt * kNCep; i += 256) dct_s[i] = (&tab->dct[0][0])[i];
 
-    // Loop-invariant per-lane constants.
-    float2 tw1[12], tw2[15], twr[8];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) tw1[k] = tab->tw1[k][lane];
-#pragma unroll
-    for (int k = 0; k < 15; ++k) tw2[k] = tab->tw2[k][lane & 15];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) twr[j] = tab->twr[j][lane];
-    const int run_start = tab->run_start[lane];
-    const int run_count = tab->run_count[lane];
-    const float run_b0 = (float)tab->run_b0[lane];
-    const float run_b1 = (float)tab->run_b1[lane];
-    const float run_inv = tab->run_inv[lane];
-    const int fl = lane < kNFilt ? lane : 0;
-    const int rise_first = tab->rise_first[fl], rise_n = tab->rise_n[fl];
-    const int fall_first = tab->fall_first[fl], fall_n = tab->fall_n[fl];
-
-    const float run_w0 = ((float)run_start - run_b0) * run_inv;      // rising weight of the run's first bin
-    const float run_f0 = (run_b1 - (float)run_start) * run_inv;      // falling weight of the run's first bin
-    // untangle partner of bin k = k1 + 4 q1 + 64 jj: Zt[(15 - jj + pd) & 15][plane]
-    const int k1l = lane >> 4, q1l = lane & 15;
-    const int plane = k1l ? 16 * (4 - k1l) + 15 - q1l : (q1l ? 16 - q1l : 0);
-    const int pd = (lane == 0) ? 1 : 0;
-    const int kbase = k1l + 4 * q1l;
-
+    LaneConst K;
+    load_lane_const(K, tab, lane);
     __syncthreads();
 
     int nfr = 0;                                            // frames this wave produced (wave-uniform)
@@ -211,149 +101,22 @@ __global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict_
         const int jl = wave + it * kWavesPerBlock;          // frame index inside the block
         if (j0 + jl >= n_s) break;
         nfr = it + 1;
-
-        // ---- load + pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj.  Frame jl covers staged
-        // rows jl+1 .. jl+4; the sample one row (480 samples) earlier is 240 dwords back.  The row in
-        // front of a slice's first aligned row is staged as zeros, which leaves that row un-emphasised
-        // exactly as the reference's 2-D preemphasis does. ----
-        float2 v[16];
-        {
-            const int* cur_p = stage + (jl + 1) * (kFrame / 2) + lane;
-#pragma unroll
-            for (int jj = 0; jj < 15; ++jj) {
-                const int cur = cur_p[64 * jj];
-                const int prv = cur_p[64 * jj - kFrame / 2];
-                const float x0 = fmaf(-0.97f, (float)(short)(prv & 0xFFFF), (float)(short)(cur & 0xFFFF));
-                const float x1 = fmaf(-0.97f, (float)(prv >> 16), (float)(cur >> 16));
-                v[jj] = make_float2(x0, x1);
-            }
-            v[15] = make_float2(0.0f, 0.0f);                // samples 1920..2047 are zero padding
-        }
-
-        // ---- pass A: radix 4 over n1 = jj >> 2; outputs k1 land in v[4 k1 + b] ----
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
-#pragma unroll
-        for (int k = 0; k < 12; ++k) v[4 + k] = cmul(v[4 + k], tw1[k]);
-
-        // ---- exchange 1: [k1][n2 = lane + 64 b] -> lane (k1, c) reads n2 = c + 16 m ----
-#pragma unroll
-        for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) ex[k1 * kEx1Stride + lane + 64 * b] = v[4 * k1 + b];
-        wave_lds_fence();
-        {
-            const float2* rd = ex + k1l * kEx1Stride + q1l;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = rd[16 * m];
-        }
-        wave_lds_fence();
-
-        // ---- pass B: radix 16 over m; twiddle W256^(c q1) ----
-        dft16(v);
-#pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw2[k - 1]);
-
-        // ---- exchange 2: [k1][q1][c] -> lane (k1, q1) reads c = 0..15 ----
-        {
-            float2* wr = ex + k1l * kEx2Plane + q1l;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) wr[17 * q] = v[q];
-        }
-        wave_lds_fence();
-        {
-            const float2* rd = ex + k1l * kEx2Plane + 17 * q1l;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) v[c] = rd[c];
-        }
-        wave_lds_fence();
-
-        // ---- pass C: radix 16 over c; register q2 now holds Z[k1 + 4 q1 + 64 q2] ----
-        dft16(v);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) ex[64 * q + lane] = v[q];             // Zt[q2][lane]
-        wave_lds_fence();
-
-        // ---- real-input untangle on the pairs (k, 1024 - k), k = k1 + 4 q1 + 64 jj < 512:
-        //      with E = Z[k] + conj(Z[N-k]), O = Z[k] - conj(Z[N-k]), T = W2048^k O,
-        //      4 |X[k]|^2 = |E - iT|^2 and 4 |X[N-k]|^2 = |E + iT|^2 ----
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const float2 a = ex[64 * jj + lane];
-            const float2 b = ex[64 * ((15 - jj + pd) & 15) + plane];
-            const float2 e = make_float2(a.x + b.x, a.y - b.y);
-            const float2 o = make_float2(a.x - b.x, a.y + b.y);
-            const float2 t = cmul(twr[jj], o);
-            const float ar = e.x + t.y, ai = e.y - t.x;                   // E - iT
-            const float br = e.x - t.y, bi = e.y + t.x;                   // E + iT
-            const int k = kbase + 64 * jj;
-            pw[k] = (ar * ar + ai * ai) * (0.25f / 2048.0f);
-            pw[1024 - k] = (br * br + bi * bi) * (0.25f / 2048.0f);
-        }
-        if (lane == 0) {                                                  // the self-paired bin 512
-            const float2 a = ex[64 * 8];
-            pw[512] = (a.x * a.x + a.y * a.y) * (1.0f / 2048.0f);
-        }
-        wave_lds_fence();
-
-        // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the
-        // 20 reads issue back to back, lanes past their run add zeros) ----
-        {
-            float sr = 0.0f, sf = 0.0f;
-            const float* run = pw + run_start;
-#pragma unroll
-            for (int i = 0; i < kMaxRun; ++i) {
-                const float p = (i < run_count) ? run[i] : 0.0f;
-                sr = fmaf(p, fmaf((float)i, run_inv, run_w0), sr);
-                sf = fmaf(p, fmaf(-(float)i, run_inv, run_f0), sf);
-            }
-            part_r[lane] = sr;                                            // ex is free again (Z consumed)
-            part_f[lane] = sf;
-        }
-        wave_lds_fence();
-
-        // ---- filter f = rising parts of segment f + falling parts of segment f+1, fixed order ----
-        {
-            float e = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) e += (i < rise_n) ? part_r[min(rise_first + i, 63)] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) e += (i < fall_n) ? part_f[min(fall_first + i, 63)] : 0.0f;
-            if (lane < 32) en[it * 32 + lane] = e;
-        }
-        wave_lds_fence();
+        // frame jl covers staged rows jl+1 .. jl+4
+        frame_energies(stage + (jl + 1) * (kFrame / 2) + lane, false, K, ex, pw, en + it * 32, lane);
     }
-
-    // ---- tail for the wave's (up to) 4 frames at once: log of the 26 energies, lifted DCT-II ----
-#pragma unroll
-    for (int r = 0; r < kFramesPerWave / 2; ++r) {
-        const int it = 2 * r + (lane >> 5), f = lane & 31;
-        if (f < kNFilt && it < nfr) {
-            const float e = en[it * 32 + f];
-            logv[it * kNFilt + f] = log(e == 0.0f ? 2.220446049250313e-16 : (double)e);   // psf.fbank clamp
-        }
-    }
-    wave_lds_fence();
-    if (lane < kFramesPerWave * kNCep) {
-        const int it = lane / kNCep, k = lane - it * kNCep;
-        if (it < nfr) {
-            double c = 0.0;
-#pragma unroll
-            for (int n = 0; n < kNFilt; ++n) c = fma(logv[it * kNFilt + n], dct_s[n * kNCep + k], c);
-            const long g = s * frames_per_slice + j0 + wave + it * kWavesPerBlock;
-            out[g * out_ld + k] = (float)c;
-        }
-    }
+    cepstra_tail(en, reinterpret_cast<double*>(wbase), dct_s, nfr, lane, out, out_ld,
+                 s * frames_per_slice + j0 + wave, kWavesPerBlock);
 }
 
 // delta[g] = (-2 f[g-2] - f[g-1] + f[g+1] + 2 f[g+2]) / 10 with the slice's own edge rows
 // replicated (python_speech_features.delta(feat, 2), core/process_data.py:277).
 __global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ mfcc, long mfcc_ld, long n_frames,
-                                                    long frames_per_slice, float* __restrict__ delta, long delta_ld) {
+                                                    long frames_per_slice, float* __restrict__ delta, long delta_ld,
+                                                    long g_first, long g_count) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_frames * kNCep) return;
-    const long g = idx / kNCep;
-    const int c = (int)(idx - g * kNCep);
+    if (idx >= g_count * kNCep) return;
+    const long g = g_first + idx / kNCep;
+    const int c = (int)(idx % kNCep);
     const long s = g / frames_per_slice;
     const long lo = s * frames_per_slice;
     long hi = lo + frames_per_slice - 1;
@@ -441,6 +204,13 @@ MfccTables* g_tables[kMaxDevices] = {nullptr};
 
 }  // namespace
 
+const fe::MfccTables* mfcc_tables_for_current_device() {
+    if (ensure_mfcc_tables() != VAD_OK) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return g_tables[dev];
+}
+
 int ensure_mfcc_tables() {
     int dev = 0;
     VAD_HIP_CHECK(hipGetDevice(&dev));
@@ -460,6 +230,20 @@ int ensure_mfcc_tables() {
     return VAD_OK;
 }
 
+}  // namespace vad
+
+namespace vad {
+// delta rows [g_first, g_first + g_count) of a stream of n_frames frames cut into frames_per_slice slices
+int launch_delta(const float* mfcc_dev, long mfcc_ld, long n_frames, long frames_per_slice, float* delta_dev,
+                 long delta_ld, long g_first, long g_count, hipStream_t st) {
+    if (g_count <= 0) return VAD_OK;
+    const long dblocks = (g_count * kNCep + 255) / 256;
+    VAD_REQUIRE(dblocks <= 0x7FFFFFFFL, "too many frames for one launch");
+    hipLaunchKernelGGL(delta_kernel, dim3((unsigned)dblocks), dim3(256), 0, st, mfcc_dev, mfcc_ld, n_frames,
+                       frames_per_slice, delta_dev, delta_ld, g_first, g_count);
+    VAD_HIP_CHECK(hipGetLastError());
+    return VAD_OK;
+}
 }  // namespace vad
 
 extern "C" int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, int64_t frames_per_slice,
@@ -487,11 +271,5 @@ extern "C" int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, i
                        (long)frames_per_slice, (long)last_slice_frames, (long)slice_stride, (int)bps, mfcc_dev,
                        (long)mfcc_ld);
     VAD_HIP_CHECK(hipGetLastError());
-    const long dthreads = n_frames * kNCep;
-    const long dblocks = (dthreads + 255) / 256;
-    VAD_REQUIRE(dblocks <= 0x7FFFFFFFL, "too many frames for one launch");
-    hipLaunchKernelGGL(delta_kernel, dim3((unsigned)dblocks), dim3(256), 0, st, mfcc_dev, (long)mfcc_ld, n_frames,
-                       (long)frames_per_slice, delta_dev, (long)delta_ld);
-    VAD_HIP_CHECK(hipGetLastError());
-    return VAD_OK;
+    return launch_delta(mfcc_dev, mfcc_ld, n_frames, frames_per_slice, delta_dev, delta_ld, 0, n_frames, st);
 }

@@ -1,0 +1,284 @@
+// Device-side building blocks of the MFCC front end, shared by the stand-alone kernel (mfcc.hip)
+// and the fused front-end + recurrent-model kernel (fused.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vad_internal.h"
+
+namespace vad {
+namespace fe {
+
+constexpr int kFrame = VAD_FRAME_SIZE;        // 480
+constexpr int kNFilt = 26;
+constexpr int kNCep = VAD_NUM_CEPS;           // 12
+constexpr int kFramesPerWave = 4;              // frames whose log/DCT tail a wave batches
+constexpr int kMaxRun = 20;                   // bins per lane in the mel stage
+constexpr int kEx1Stride = 272;               // exchange 1: complex elements per k1 row (256 + 16: the two
+                                              // k1 rows of a 32-lane half land on opposite bank halves)
+constexpr int kEx2Plane = 273;                // exchange 2: complex elements per k1 plane, 17 per q1 row
+constexpr int kExBytes = 8736;                // >= 4*272*8, >= (3*273 + 15*17 + 16)*8, >= 1024*8
+constexpr int kPowFloats = 1056;              // P[0..1024] plus slack for reads past a lane's run
+
+struct MfccTables {
+    float2 tw1[12][64];      // [(k1-1)*4 + b][lane]  W1024^((lane + 64 b) * k1)
+    float2 tw2[15][16];      // [q1-1][c]             W256^(c * q1)
+    float2 twr[8][64];       // [jj][lane]            W2048^(k1 + 4 q1 + 64 jj), lane = 16 k1 + q1
+    int run_start[64];       // mel stage: first bin of the lane's run
+    int run_count[64];       //            bins in the run (0 for idle lanes)
+    int run_b0[64];          //            first bin of the run's segment
+    int run_b1[64];          //            one past the last bin of the segment
+    float run_inv[64];       //            1 / (b1 - b0)
+    int rise_first[kNFilt];  // filter f = rising parts of lanes [rise_first, +rise_n)
+    int rise_n[kNFilt];
+    int fall_first[kNFilt];  //          + falling parts of lanes [fall_first, +fall_n)
+    int fall_n[kNFilt];
+    double dct[kNFilt][kNCep];   // sqrt(2/26) * lifter(k) * cos(pi k (2n+1) / 52), k = 1..12
+};
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+
+// Forward 4-point DFT in place (W4 = -i).
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3);
+    const float2 d = csub(a1, a3);
+    const float2 t3 = make_float2(d.y, -d.x);          // (a1 - a3) * (-i)
+    a0 = cadd(t0, t2);
+    a1 = cadd(t1, t3);
+    a2 = csub(t0, t2);
+    a3 = csub(t1, t3);
+}
+
+// Forward 16-point DFT in place, natural order in and out.
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128673848f;      // cos(pi/8)
+    constexpr float S1 = 0.38268343236508978178f;      // sin(pi/8)
+    constexpr float R2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // v[4c + b] *= W16^(b c)
+    v[5] = cmul(v[5], make_float2(C1, -S1));           // b=1 c=1
+    v[9] = cmul(v[9], make_float2(R2, -R2));           // b=1 c=2
+    v[13] = cmul(v[13], make_float2(S1, -C1));         // b=1 c=3
+    v[6] = cmul(v[6], make_float2(R2, -R2));           // b=2 c=1
+    v[10] = make_float2(v[10].y, -v[10].x);            // b=2 c=2  (-i)
+    v[14] = cmul(v[14], make_float2(-R2, -R2));        // b=2 c=3
+    v[7] = cmul(v[7], make_float2(S1, -C1));           // b=3 c=1
+    v[11] = cmul(v[11], make_float2(-R2, -R2));        // b=3 c=2
+    v[15] = cmul(v[15], make_float2(-C1, S1));         // b=3 c=3  W16^9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dft4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    // X[c + 4 d] sits at v[4 c + d]: transpose the 4x4 register block.
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = c + 1; d < 4; ++d) {
+            const float2 t = v[4 * c + d];
+            v[4 * c + d] = v[4 * d + c];
+            v[4 * d + c] = t;
+        }
+}
+
+// LDS traffic below is between lanes of ONE wave.  LDS operations of a wave
+// complete in issue order, so only the compiler has to be kept from moving
+// loads above the stores of other lanes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
+// Per-wave LDS: [exchange / Zt / partial sums / log energies][power spectrum][filter energies of 4 frames]
+constexpr int kWaveLdsBytes = kExBytes + kPowFloats * 4 + kFramesPerWave * 32 * 4;
+
+// Loop-invariant per-lane constants (about 90 VGPRs).
+struct LaneConst {
+    float2 tw1[12], tw2[15], twr[8];
+    int run_start, run_count;
+    float run_inv, run_w0, run_f0;
+    int rise_first, rise_n, fall_first, fall_n;
+    int k1l, q1l, plane, pd, kbase;
+};
+
+__device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* __restrict__ tab, int lane) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) K.tw1[k] = tab->tw1[k][lane];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) K.tw2[k] = tab->tw2[k][lane & 15];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) K.twr[j] = tab->twr[j][lane];
+    K.run_start = tab->run_start[lane];
+    K.run_count = tab->run_count[lane];
+    const float b0 = (float)tab->run_b0[lane], b1 = (float)tab->run_b1[lane];
+    K.run_inv = tab->run_inv[lane];
+    K.run_w0 = ((float)K.run_start - b0) * K.run_inv;      // rising weight of the run's first bin
+    K.run_f0 = (b1 - (float)K.run_start) * K.run_inv;      // falling weight of the run's first bin
+    const int fl = lane < kNFilt ? lane : 0;
+    K.rise_first = tab->rise_first[fl];
+    K.rise_n = tab->rise_n[fl];
+    K.fall_first = tab->fall_first[fl];
+    K.fall_n = tab->fall_n[fl];
+    // untangle partner of bin k = k1 + 4 q1 + 64 jj: Zt[(15 - jj + pd) & 15][plane]
+    K.k1l = lane >> 4;
+    K.q1l = lane & 15;
+    K.plane = K.k1l ? 16 * (4 - K.k1l) + 15 - K.q1l : (K.q1l ? 16 - K.q1l : 0);
+    K.pd = (lane == 0) ? 1 : 0;
+    K.kbase = K.k1l + 4 * K.q1l;
+}
+
+// One frame: `cur_p` points (in LDS) at this lane's first int16 pair of the frame's first row; rows are
+// contiguous, the row 240 dwords earlier is the pre-emphasis predecessor.  With zero_first_pred the
+// predecessor of the frame's FIRST row is taken as zero (first frame of a slice: that row is not
+// pre-emphasised, as in the reference's 2-D preemphasis); callers that stage a zero row there pass false.
+// Writes the 26 mel filter energies to en_slot[0..25].
+__device__ __forceinline__ void frame_energies(const int* cur_p, bool zero_first_pred, const LaneConst& K, float2* ex,
+                                               float* pw, float* en_slot, int lane) {
+    float* part_r = reinterpret_cast<float*>(ex);                           // aliases ex once Z is consumed
+    float* part_f = part_r + 64;
+
+    // ---- load + pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj ----
+    float2 v[16];
+#pragma unroll
+    for (int jj = 0; jj < 15; ++jj) {
+        const int cur = cur_p[64 * jj];
+        int prv = cur_p[64 * jj - kFrame / 2];
+        if (jj < 4 && zero_first_pred && (lane + 64 * jj) < kFrame / 2) prv = 0;
+        const float x0 = fmaf(-0.97f, (float)(short)(prv & 0xFFFF), (float)(short)(cur & 0xFFFF));
+        const float x1 = fmaf(-0.97f, (float)(prv >> 16), (float)(cur >> 16));
+        v[jj] = make_float2(x0, x1);
+    }
+    v[15] = make_float2(0.0f, 0.0f);                        // samples 1920..2047 are zero padding
+
+    // ---- pass A: radix 4 over n1 = jj >> 2; outputs k1 land in v[4 k1 + b] ----
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[4 + k] = cmul(v[4 + k], K.tw1[k]);
+
+    // ---- exchange 1: [k1][n2 = lane + 64 b] -> lane (k1, c) reads n2 = c + 16 m ----
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ex[k1 * kEx1Stride + lane + 64 * b] = v[4 * k1 + b];
+    wave_lds_fence();
+    {
+        const float2* rd = ex + K.k1l * kEx1Stride + K.q1l;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = rd[16 * m];
+    }
+    wave_lds_fence();
+
+    // ---- pass B: radix 16 over m; twiddle W256^(c q1) ----
+    dft16(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], K.tw2[k - 1]);
+
+    // ---- exchange 2: [k1][q1][c] -> lane (k1, q1) reads c = 0..15 ----
+    {
+        float2* wr = ex + K.k1l * kEx2Plane + K.q1l;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wr[17 * q] = v[q];
+    }
+    wave_lds_fence();
+    {
+        const float2* rd = ex + K.k1l * kEx2Plane + 17 * K.q1l;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = rd[c];
+    }
+    wave_lds_fence();
+
+    // ---- pass C: radix 16 over c; register q2 now holds Z[k1 + 4 q1 + 64 q2] ----
+    dft16(v);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ex[64 * q + lane] = v[q];                 // Zt[q2][lane]
+    wave_lds_fence();
+
+    // ---- real-input untangle on the pairs (k, 1024 - k), k = k1 + 4 q1 + 64 jj < 512:
+    //      with E = Z[k] + conj(Z[N-k]), O = Z[k] - conj(Z[N-k]), T = W2048^k O,
+    //      4 |X[k]|^2 = |E - iT|^2 and 4 |X[N-k]|^2 = |E + iT|^2 ----
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const float2 a = ex[64 * jj + lane];
+        const float2 b = ex[64 * ((15 - jj + K.pd) & 15) + K.plane];
+        const float2 e = make_float2(a.x + b.x, a.y - b.y);
+        const float2 o = make_float2(a.x - b.x, a.y + b.y);
+        const float2 t = cmul(K.twr[jj], o);
+        const float ar = e.x + t.y, ai = e.y - t.x;                       // E - iT
+        const float br = e.x - t.y, bi = e.y + t.x;                       // E + iT
+        const int k = K.kbase + 64 * jj;
+        pw[k] = (ar * ar + ai * ai) * (0.25f / 2048.0f);
+        pw[1024 - k] = (br * br + bi * bi) * (0.25f / 2048.0f);
+    }
+    if (lane == 0) {                                                      // the self-paired bin 512
+        const float2 a = ex[64 * 8];
+        pw[512] = (a.x * a.x + a.y * a.y) * (1.0f / 2048.0f);
+    }
+    wave_lds_fence();
+
+    // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the
+    // 20 reads issue back to back, lanes past their run add zeros) ----
+    {
+        float sr = 0.0f, sf = 0.0f;
+        const float* run = pw + K.run_start;
+#pragma unroll
+        for (int i = 0; i < kMaxRun; ++i) {
+            const float p = (i < K.run_count) ? run[i] : 0.0f;
+            sr = fmaf(p, fmaf((float)i, K.run_inv, K.run_w0), sr);
+            sf = fmaf(p, fmaf(-(float)i, K.run_inv, K.run_f0), sf);
+        }
+        part_r[lane] = sr;                                                // ex is free again (Z consumed)
+        part_f[lane] = sf;
+    }
+    wave_lds_fence();
+
+    // ---- filter f = rising parts of segment f + falling parts of segment f+1, fixed order ----
+    {
+        float e = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) e += (i < K.rise_n) ? part_r[min(K.rise_first + i, 63)] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) e += (i < K.fall_n) ? part_f[min(K.fall_first + i, 63)] : 0.0f;
+        if (lane < 32) en_slot[lane] = e;
+    }
+    wave_lds_fence();
+}
+
+// Tail for up to 4 frames of one wave at once: log of the 26 energies (fp64), lifted DCT-II (fp64).
+// Frame `it` goes to output row g0 + it * gstep.  `logv` may alias the exchange region.
+__device__ __forceinline__ void cepstra_tail(const float* en, double* logv, const double* dct_s, int nfr, int lane,
+                                             float* __restrict__ out, long out_ld, long g0, long gstep) {
+#pragma unroll
+    for (int r = 0; r < kFramesPerWave / 2; ++r) {
+        const int it = 2 * r + (lane >> 5), f = lane & 31;
+        if (f < kNFilt && it < nfr) {
+            const float e = en[it * 32 + f];
+            logv[it * kNFilt + f] = log(e == 0.0f ? 2.220446049250313e-16 : (double)e);   // psf.fbank clamp
+        }
+    }
+    wave_lds_fence();
+    if (lane < kFramesPerWave * kNCep) {
+        const int it = lane / kNCep, k = lane - it * kNCep;
+        if (it < nfr) {
+            double c = 0.0;
+#pragma unroll
+            for (int n = 0; n < kNFilt; ++n) c = fma(logv[it * kNFilt + n], dct_s[n * kNCep + k], c);
+            out[(g0 + it * gstep) * out_ld + k] = (float)c;
+        }
+    }
+    wave_lds_fence();
+}
+
+}  // namespace fe
+
+// Device copy of the constant tables for the current device (created on first use); mfcc.hip.
+const fe::MfccTables* mfcc_tables_for_current_device();
+
+}  // namespace vad

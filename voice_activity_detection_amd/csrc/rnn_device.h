@@ -1,0 +1,145 @@
+// Device-side building blocks of the GRU / LSTM window models, shared by rnn.hip and fused.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vad_internal.h"
+
+namespace vad {
+namespace rnn {
+
+constexpr int kT = VAD_FRAMES;      // 30 steps
+constexpr int kF = VAD_FEATURES;    // 24 features
+constexpr int kKs = kF / 2;         // 12 k-steps of the input projection
+constexpr int kHp = 32;             // padded hidden size (one 32-row tile per gate)
+constexpr int kHk = kHp / 2;        // 16 k-steps of the recurrent product
+constexpr int kL1 = 26;             // lin1 outputs
+constexpr int kWindowsPerWave = 32;
+constexpr int kWavesPerBlock = 4;   // rnn_kernel
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Blob layout in floats; shared by the host packer and the kernels.  `ut` = number of 32-unit
+// tiles covering the hidden size (1 for the reference's H = 30, 3 for H = 90).
+struct NetLayout {
+    int gates;        // 3 GRU, 4 LSTM
+    int ut;
+    int a_ih;         // [gates][ut][12][64]        A operands of the input projection
+    int a_hh;         // [gates][ut][ut*16][64]     A operands of the recurrent product
+    int cb;           // [4][ut][2][16]             accumulator initial values (biases), per lane half
+    int head;         // a1 [30][ut*16][64]         A operands of lin1 (large) or lin (small, rows 0-1)
+    int tail;         // large: b1e [2][16], w2e [2][2][16], b2 [2] (+2 pad); small: bl [2] (+2 pad)
+    int total;
+};
+
+__host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 1) {
+    NetLayout L;
+    L.gates = lstm ? 4 : 3;
+    L.ut = ut;
+    L.a_ih = 0;
+    L.a_hh = L.a_ih + L.gates * ut * kKs * 64;
+    L.cb = L.a_hh + L.gates * ut * ut * kHk * 64;
+    L.head = L.cb + 4 * ut * 2 * 16;
+    L.tail = L.head + kT * ut * kHk * 64;
+    L.total = L.tail + (large ? (2 * 16 + 2 * 2 * 16 + 4) : 4);
+    return L;
+}
+
+__host__ __device__ inline int unit_tiles(int hidden) { return (hidden + 31) / 32; }
+
+__device__ __forceinline__ float fast_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x16 load16(const float* p) {      // 16 consecutive floats, 16-byte aligned
+    const float4* s = reinterpret_cast<const float4*>(p);
+    f32x16 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = s[q];
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+    return r;
+}
+
+// Recurrent product for one step: acc += W_hh . h  (GRU keeps W_hn h + b_hn apart in acc[3]).
+template <bool LSTM>
+__device__ __forceinline__ void recurrent_mfma(f32x16 (&acc)[4], const f32x16& h, const float* a_hh, int lane) {
+#pragma unroll
+    for (int i = 0; i < kHk; ++i) {
+        const float hv = h[i];
+        if (LSTM) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = MFMA(a_hh[(g * kHk + i) * 64 + lane], hv, acc[g]);
+        } else {
+            acc[0] = MFMA(a_hh[(0 * kHk + i) * 64 + lane], hv, acc[0]);
+            acc[1] = MFMA(a_hh[(1 * kHk + i) * 64 + lane], hv, acc[1]);
+            acc[3] = MFMA(a_hh[(2 * kHk + i) * 64 + lane], hv, acc[3]);
+        }
+    }
+}
+
+// Gate non-linearities, elementwise in (unit, window).
+template <bool LSTM>
+__device__ __forceinline__ void gate_update(const f32x16 (&acc)[4], f32x16& h, f32x16& c) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (LSTM) {
+            const float ig = fast_sigmoid(acc[0][i]);
+            const float fg = fast_sigmoid(acc[1][i]);
+            const float gg = fast_tanh(acc[2][i]);
+            const float og = fast_sigmoid(acc[3][i]);
+            const float cn = fmaf(fg, c[i], ig * gg);
+            c[i] = cn;
+            h[i] = og * fast_tanh(cn);
+        } else {
+            const float r = fast_sigmoid(acc[0][i]);
+            const float z = fast_sigmoid(acc[1][i]);
+            const float n = fast_tanh(fmaf(r, acc[3][i], acc[2][i]));
+            h[i] = fmaf(z, h[i] - n, n);
+        }
+    }
+}
+
+// (ReLU, lin2) or the bias of lin; softmax over the 2 classes; decision.
+template <bool LARGE>
+__device__ __forceinline__ void head_epilogue(const f32x16& lacc, const float* __restrict__ tail, int half, long w,
+                                              long n_windows, float* __restrict__ p_out, uint8_t* __restrict__ dec_out,
+                                              int mode, float threshold) {
+    float l0, l1;
+    if (LARGE) {
+        const float* b1e = tail + half * 16;
+        const float* w2a = tail + 32 + (0 * 2 + half) * 16;
+        const float* w2b = tail + 32 + (1 * 2 + half) * 16;
+        l0 = l1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = fmaxf(lacc[i] + b1e[i], 0.0f);
+            l0 = fmaf(v, w2a[i], l0);
+            l1 = fmaf(v, w2b[i], l1);
+        }
+        l0 += __shfl_xor(l0, 32, 64);
+        l1 += __shfl_xor(l1, 32, 64);
+        l0 += tail[96];
+        l1 += tail[97];
+    } else {
+        l0 = lacc[0] + tail[0];          // rows 0 and 1 of the tile live in lane half 0
+        l1 = lacc[1] + tail[1];
+    }
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float inv = 1.0f / (e0 + e1);
+    const float p0 = e0 * inv, p1 = e1 * inv;
+    if (half == 0 && w < n_windows) {
+        *reinterpret_cast<float2*>(p_out + 2 * w) = make_float2(p0, p1);
+        if (dec_out) dec_out[w] = (mode == VAD_DECIDE_THRESHOLD) ? (p1 >= threshold) : (p1 > p0);
+    }
+}
+
+}  // namespace rnn
+}  // namespace vad
