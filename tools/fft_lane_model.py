@@ -29,7 +29,7 @@ def dft16(v):
 
 
 S1 = 272    # exchange-1 row stride (complex)
-S2 = 273    # exchange-2 plane stride (complex); row stride 17
+S2 = 272    # exchange-2 plane stride (complex); row stride 17
 
 
 def fft1024_lanes(z):

@@ -16,8 +16,9 @@ constexpr int kFramesPerWave = 4;              // frames whose log/DCT tail a wa
 constexpr int kMaxRun = 20;                   // bins per lane in the mel stage
 constexpr int kEx1Stride = 272;               // exchange 1: complex elements per k1 row (256 + 16: the two
                                               // k1 rows of a 32-lane half land on opposite bank halves)
-constexpr int kEx2Plane = 273;                // exchange 2: complex elements per k1 plane, 17 per q1 row
-constexpr int kExBytes = 8736;                // >= 4*272*8, >= (3*273 + 15*17 + 16)*8, >= 1024*8
+constexpr int kEx2Plane = 272;                // exchange 2: complex elements per k1 plane (16 rows of 17): the two
+                                              // planes of a 32-lane half interleave on the 64 banks
+constexpr int kExBytes = 8704;                // = 4*272*8 >= (3*272 + 15*17 + 16)*8, >= 1024*8
 constexpr int kPowFloats = 1056;              // P[0..1024] plus slack for reads past a lane's run
 
 struct MfccTables {

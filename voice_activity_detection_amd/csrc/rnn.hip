@@ -49,7 +49,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // any window stride
 
-template <bool LSTM, bool LARGE>
+template <bool LSTM, bool LARGE, int KS>
 __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x, long n_windows, long wstride,
                                                      const float* __restrict__ blob, float* __restrict__ p_out,
                                                      uint8_t* __restrict__ dec_out, int mode, float threshold) {
@@ -99,14 +99,14 @@ __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x
             for (int g = 0; g < G; ++g) acc[g] = MFMA(a_ih[(g * kKs + s) * 64 + lane], xv[s], acc[g]);
         }
         // recurrent product, K = 32: k-step i takes unit u(i, half) = the lane's own h[i]; h_0 = 0
-        if (t > 0) recurrent_mfma<LSTM>(acc, h, a_hh, lane);
-        float a1v[16];                                   // issued here, consumed after the gate math
+        if (t > 0) recurrent_mfma<LSTM, KS>(acc, h, a_hh, lane);
+        float a1v[KS];                                   // issued here, consumed after the gate math
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
+        for (int i = 0; i < KS; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
         gate_update<LSTM>(acc, h, c);
         // head: flatten index is t * H + unit
 #pragma unroll
-        for (int i = 0; i < 16; ++i) lacc = MFMA(a1v[i], h[i], lacc);
+        for (int i = 0; i < KS; ++i) lacc = MFMA(a1v[i], h[i], lacc);
     }
     head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
 }
@@ -126,7 +126,7 @@ struct StreamCfg {
     static constexpr int lds_floats = gi_floats + G * kHk * 64 + 4 * 2 * 16;
 };
 
-template <bool LSTM, bool LARGE>
+template <bool LSTM, bool LARGE, int KS>
 __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel(
     const float* __restrict__ feat, long n_windows, const float* __restrict__ blob, float* __restrict__ p_out,
     uint8_t* __restrict__ dec_out, int mode, float threshold) {
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
     const float* girow = gi + (wave * kWindowsPerWave + col) * C::rs + 4 * half;
 
     for (int t = 0; t < kT; ++t) {
-        float a1v[16];
+        float a1v[KS];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
+        for (int i = 0; i < KS; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
         f32x16 acc[4];
         const float* src = girow + t * C::rs;
 #pragma unroll
@@ -188,10 +188,10 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
                 acc[g][4 * q] = v.x; acc[g][4 * q + 1] = v.y; acc[g][4 * q + 2] = v.z; acc[g][4 * q + 3] = v.w;
             }
         if (!LSTM) acc[3] = load16(cb + (3 * 2 + half) * 16);    // b_hn
-        if (t > 0) recurrent_mfma<LSTM>(acc, h, a_hh, lane);
+        if (t > 0) recurrent_mfma<LSTM, KS>(acc, h, a_hh, lane);
         gate_update<LSTM>(acc, h, c);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) lacc = MFMA(a1v[i], h[i], lacc);
+        for (int i = 0; i < KS; ++i) lacc = MFMA(a1v[i], h[i], lacc);
     }
     head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
 }
@@ -263,9 +263,9 @@ __global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restric
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float r = fast_sigmoid(acc[0][i]);
-                const float z = fast_sigmoid(acc[1][i]);
-                const float n = fast_tanh(fmaf(r, acc[3][i], acc[2][i]));
+                const float r = sigmoid_pre(acc[0][i]);
+                const float z = sigmoid_pre(acc[1][i]);
+                const float n = tanh_pre(fmaf(r, acc[3][i], acc[2][i]));
                 hn[mt][i] = fmaf(z, h[mt][i] - n, n);
             }
         }
@@ -297,10 +297,14 @@ int ensure_rnn_attrs() {
     if (dev < 0 || dev >= 64) return VAD_OK;
     if (done[dev]) return VAD_OK;
     int rc = VAD_OK;
-    if ((rc = allow_lds(&rnn_stream_kernel<false, false>, StreamCfg<false>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_kernel<false, true>, StreamCfg<false>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_kernel<true, false>, StreamCfg<true>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_kernel<true, true>, StreamCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<false, false, 15>, StreamCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<false, true, 15>, StreamCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<true, false, 15>, StreamCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<true, true, 15>, StreamCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<false, false, 16>, StreamCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<false, true, 16>, StreamCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<true, false, 16>, StreamCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_kernel<true, true, 16>, StreamCfg<true>::lds_floats))) return rc;
     if ((rc = allow_lds(&gru_wide_kernel<false, 2>, net_layout(false, false, 2).head))) return rc;
     if ((rc = allow_lds(&gru_wide_kernel<true, 2>, net_layout(false, true, 2).head))) return rc;
     if ((rc = allow_lds(&gru_wide_kernel<false, 3>, net_layout(false, false, 3).head))) return rc;
@@ -330,8 +334,8 @@ int launch_wide(const float* x, long n_windows, long wstride, const float* blob,
 // ---------------------------------------------------------------------------------------------
 // launchers
 
-template <bool LSTM, bool LARGE>
-int launch(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
+template <bool LSTM, bool LARGE, int KS>
+int launch_ks(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
            float threshold, hipStream_t st) {
     if (wstride == kF) {
         using C = StreamCfg<LSTM>;
@@ -340,7 +344,7 @@ int launch(const float* x, long n_windows, long wstride, const float* blob, floa
         const size_t lds_bytes = (size_t)C::lds_floats * sizeof(float);
         const long blocks = (n_windows + C::windows - 1) / C::windows;
         VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
-        hipLaunchKernelGGL((rnn_stream_kernel<LSTM, LARGE>), dim3((unsigned)blocks), dim3(C::waves * 64), lds_bytes, st, x,
+        hipLaunchKernelGGL((rnn_stream_kernel<LSTM, LARGE, KS>), dim3((unsigned)blocks), dim3(C::waves * 64), lds_bytes, st, x,
                            n_windows, blob, p, dec, mode, threshold);
         VAD_HIP_CHECK(hipGetLastError());
         return VAD_OK;
@@ -350,10 +354,18 @@ int launch(const float* x, long n_windows, long wstride, const float* blob, floa
     const long per_block = (long)kWindowsPerWave * kWavesPerBlock;
     const long blocks = (n_windows + per_block - 1) / per_block;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
-    hipLaunchKernelGGL((rnn_kernel<LSTM, LARGE>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds_bytes, st, x,
+    hipLaunchKernelGGL((rnn_kernel<LSTM, LARGE, KS>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds_bytes, st, x,
                        n_windows, wstride, blob, p, dec, mode, threshold);
     VAD_HIP_CHECK(hipGetLastError());
     return VAD_OK;
+}
+
+template <bool LSTM, bool LARGE>
+int launch(const float* x, long n_windows, long wstride, const float* blob, int hidden, float* p, uint8_t* dec, int mode,
+           float threshold, hipStream_t st) {
+    return hidden_k_steps(hidden) == kHk - 1
+               ? launch_ks<LSTM, LARGE, kHk - 1>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
+               : launch_ks<LSTM, LARGE, kHk>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
 }
 
 int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const float* blob, int hidden, int large,
@@ -370,8 +382,8 @@ int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const
     if (n_windows == 0) return VAD_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (lstm) {
-        return large ? launch<true, true>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
-                     : launch<true, false>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
+        return large ? launch<true, true>(x, n_windows, wstride, blob, hidden, p, dec, mode, threshold, st)
+                     : launch<true, false>(x, n_windows, wstride, blob, hidden, p, dec, mode, threshold, st);
     }
     if (hidden > 2 * kHp)
         return large ? launch_wide<true, 3>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
@@ -379,8 +391,8 @@ int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const
     if (hidden > kHp)
         return large ? launch_wide<true, 2>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
                      : launch_wide<false, 2>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
-    return large ? launch<false, true>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
-                 : launch<false, false>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
+    return large ? launch<false, true>(x, n_windows, wstride, blob, hidden, p, dec, mode, threshold, st)
+                 : launch<false, false>(x, n_windows, wstride, blob, hidden, p, dec, mode, threshold, st);
 }
 
 }  // namespace
@@ -407,32 +419,39 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
     VAD_REQUIRE(blob_floats >= (size_t)L.total, "blob too small: need %d floats", L.total);
     const int H = hidden, G = L.gates, KH = UT * kHk;
     memset(blob, 0, sizeof(float) * (size_t)L.total);
+    // tile row -> hidden unit (-1 = padding).  One-tile models may skip the all-padding k-step.
+    auto unit_at = [&](int tile, int r) { return UT == 1 ? unit_of_row(r, H) : (32 * tile + r < H ? 32 * tile + r : -1); };
+    // gate scale: sigmoid gates -log2 e, tanh gates 2 log2 e (GRU r,z | n ; LSTM i,f,o | g)
+    auto gate_scale = [&](int g) { return (lstm ? g == 2 : g == 2) ? kTanhScale : kSigmoidScale; };
     for (int g = 0; g < G; ++g)
         for (int mt = 0; mt < UT; ++mt)
             for (int lane = 0; lane < 64; ++lane) {
-                const int m = 32 * mt + (lane & 31), hh = lane >> 5;
-                if (m >= H) continue;
+                const int m = unit_at(mt, lane & 31), hh = lane >> 5;
+                if (m < 0) continue;
+                const double sc = gate_scale(g);
                 for (int s = 0; s < kKs; ++s)
-                    blob[L.a_ih + ((g * UT + mt) * kKs + s) * 64 + lane] = w_ih[(g * H + m) * kF + s + 12 * hh];
+                    blob[L.a_ih + ((g * UT + mt) * kKs + s) * 64 + lane] =
+                        (float)(sc * (double)w_ih[(g * H + m) * kF + s + 12 * hh]);
                 for (int ks = 0; ks < KH; ++ks) {
-                    const int u = 32 * (ks / kHk) + mfma32_row(ks % kHk, hh);
-                    if (u < H) blob[L.a_hh + ((g * UT + mt) * KH + ks) * 64 + lane] = w_hh[(g * H + m) * H + u];
+                    const int u = unit_at(ks / kHk, mfma32_row(ks % kHk, hh));
+                    if (u >= 0)
+                        blob[L.a_hh + ((g * UT + mt) * KH + ks) * 64 + lane] = (float)(sc * (double)w_hh[(g * H + m) * H + u]);
                 }
             }
     for (int mt = 0; mt < UT; ++mt)
         for (int hh = 0; hh < 2; ++hh)
             for (int i = 0; i < 16; ++i) {
-                const int u = 32 * mt + mfma32_row(i, hh);
-                if (u >= H) continue;
+                const int u = unit_at(mt, mfma32_row(i, hh));
+                if (u < 0) continue;
                 float* cb = blob + L.cb;
                 auto at = [&](int a) -> float& { return cb[((a * UT + mt) * 2 + hh) * 16 + i]; };
                 if (lstm) {
-                    for (int g = 0; g < 4; ++g) at(g) = b_ih[g * H + u] + b_hh[g * H + u];
+                    for (int g = 0; g < 4; ++g) at(g) = (float)(gate_scale(g) * ((double)b_ih[g * H + u] + (double)b_hh[g * H + u]));
                 } else {
-                    at(0) = b_ih[u] + b_hh[u];                    // r
-                    at(1) = b_ih[H + u] + b_hh[H + u];            // z
-                    at(2) = b_ih[2 * H + u];                      // W_in x + b_in
-                    at(3) = b_hh[2 * H + u];                      // W_hn h + b_hn
+                    at(0) = (float)(kSigmoidScale * ((double)b_ih[u] + (double)b_hh[u]));                  // r
+                    at(1) = (float)(kSigmoidScale * ((double)b_ih[H + u] + (double)b_hh[H + u]));          // z
+                    at(2) = (float)(kTanhScale * (double)b_ih[2 * H + u]);                                 // W_in x + b_in
+                    at(3) = (float)(kTanhScale * (double)b_hh[2 * H + u]);                                 // W_hn h + b_hn
                 }
             }
     // head: rows of lin1 (26) or lin (2) as one 32-row A tile per k-step
@@ -442,8 +461,8 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
     for (int t = 0; t < kT; ++t)
         for (int ks = 0; ks < KH; ++ks)
             for (int lane = 0; lane < 64; ++lane) {
-                const int o = lane & 31, u = 32 * (ks / kHk) + mfma32_row(ks % kHk, lane >> 5);
-                if (o < rows && u < H) head[(t * KH + ks) * 64 + lane] = hw[o * (kT * H) + t * H + u];
+                const int o = lane & 31, u = unit_at(ks / kHk, mfma32_row(ks % kHk, lane >> 5));
+                if (o < rows && u >= 0) head[(t * KH + ks) * 64 + lane] = hw[o * (kT * H) + t * H + u];
             }
     float* tail = blob + L.tail;
     if (large) {

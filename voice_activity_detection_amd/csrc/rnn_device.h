@@ -47,8 +47,29 @@ __host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 
 
 __host__ __device__ inline int unit_tiles(int hidden) { return (hidden + 31) / 32; }
 
-__device__ __forceinline__ float fast_sigmoid(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+// Placement of the hidden units on the 32 rows of a tile.  Rows (i & 3) + 8 (i >> 2) + 4 hh of
+// k-step i = 15 are rows 27 and 31; when the hidden size leaves two rows free (H <= 30, the reference
+// uses 30) those two are the padding, k-step 15 multiplies zeros only and the kernels skip it.
+__host__ __device__ inline int hidden_k_steps(int hidden) { return hidden <= 30 ? kHk - 1 : kHk; }
+__host__ __device__ inline int row_of_unit(int u, int hidden) {
+    return (hidden <= 30 && u >= 27) ? u + 1 : u;            // skips row 27; row 31 is never reached
+}
+__host__ __device__ inline int unit_of_row(int r, int hidden) {
+    if (hidden > 30) return r < hidden ? r : -1;
+    if (r == 27 || r == 31) return -1;
+    const int u = r > 27 ? r - 1 : r;
+    return u < hidden ? u : -1;
+}
+
+// The packer scales the sigmoid gates' weights and biases by -log2(e) and the tanh gates' by
+// 2 log2(e), so the pre-activations arrive ready for v_exp_f32 (2^x).
+constexpr double kSigmoidScale = -1.4426950408889634;
+constexpr double kTanhScale = 2.8853900817779268;
+__device__ __forceinline__ float sigmoid_pre(float a) {       // a = -x log2 e   ->  1 / (1 + e^-x)
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
+}
+__device__ __forceinline__ float tanh_pre(float a) {          // a = 2 x log2 e  ->  1 - 2 / (1 + e^2x)
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)), 1.0f);
 }
 __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
@@ -68,10 +89,10 @@ __device__ __forceinline__ f32x16 load16(const float* p) {      // 16 consecutiv
 }
 
 // Recurrent product for one step: acc += W_hh . h  (GRU keeps W_hn h + b_hn apart in acc[3]).
-template <bool LSTM>
+template <bool LSTM, int KS>
 __device__ __forceinline__ void recurrent_mfma(f32x16 (&acc)[4], const f32x16& h, const float* a_hh, int lane) {
 #pragma unroll
-    for (int i = 0; i < kHk; ++i) {
+    for (int i = 0; i < KS; ++i) {
         const float hv = h[i];
         if (LSTM) {
 #pragma unroll
@@ -90,17 +111,17 @@ __device__ __forceinline__ void gate_update(const f32x16 (&acc)[4], f32x16& h, f
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         if (LSTM) {
-            const float ig = fast_sigmoid(acc[0][i]);
-            const float fg = fast_sigmoid(acc[1][i]);
-            const float gg = fast_tanh(acc[2][i]);
-            const float og = fast_sigmoid(acc[3][i]);
+            const float ig = sigmoid_pre(acc[0][i]);
+            const float fg = sigmoid_pre(acc[1][i]);
+            const float gg = tanh_pre(acc[2][i]);
+            const float og = sigmoid_pre(acc[3][i]);
             const float cn = fmaf(fg, c[i], ig * gg);
             c[i] = cn;
             h[i] = og * fast_tanh(cn);
         } else {
-            const float r = fast_sigmoid(acc[0][i]);
-            const float z = fast_sigmoid(acc[1][i]);
-            const float n = fast_tanh(fmaf(r, acc[3][i], acc[2][i]));
+            const float r = sigmoid_pre(acc[0][i]);
+            const float z = sigmoid_pre(acc[1][i]);
+            const float n = tanh_pre(fmaf(r, acc[3][i], acc[2][i]));
             h[i] = fmaf(z, h[i] - n, n);
         }
     }
