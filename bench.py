@@ -99,11 +99,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
         args.gpus = world
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a GPU when rehearsing the
+    # multi-rank path on a one-GPU box (timing is then meaningless, the control flow is not)
+    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+    local = local % max(torch.cuda.device_count(), 1) if backend == 'gloo' else local
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
+    red_dev = 'cuda' if backend == 'nccl' else 'cpu'
 
     import voice_activity_detection_amd as pkg
     from voice_activity_detection_amd.sharding import shard_plan
@@ -145,10 +153,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([plan['n_own']], dtype=torch.int64, device='cuda')
+        tot = torch.tensor([plan['n_own']], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot)
         total_frames = int(tot.item())
     else:

@@ -138,3 +138,53 @@ def test_large_stream_properties(vad):
         _, rm, rd = mfcc_ref.process_test_frames(aligned[3:], aligned[:3])
         assert_feat_close(feat[lo:hi, :12].cpu().numpy(), rm, 'mfcc slice %d' % s)
         assert_feat_close(feat[lo:hi, 12:].cpu().numpy(), rd, 'delta slice %d' % s)
+
+
+def test_full_size_stream_properties(vad):
+    """BASELINE configuration size: 100 h = 12 M frames (11.5 GB of int16) through the whole path.
+    The oracle cannot sweep this, so the checks are size-independent properties: determinism,
+    slice independence (any slice recomputed alone reproduces the big run bit for bit), window
+    independence (any window recomputed from a materialised batch reproduces its posterior bit for
+    bit), oracle parity on spot slices, and well-formed outputs."""
+    from oracle import models_ref
+    n = 12_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 20 * 2 ** 30:
+        pytest.skip('needs 20 GB of free device memory')
+    ref = models_ref.make_model('gru_large')
+    net = vad.Net(large=True, lstm=False)
+    net.load_state_dict(ref.state_dict())
+    stream = vad.synth_stream(0, n, seed=1337)
+    ws = vad.StreamWorkspace(n, stream.device)
+    feat, p, dec = vad.vad_stream(net, stream, n, workspace=ws)
+    torch.cuda.synchronize()
+    assert p.shape == (n - 29, 2) and dec.shape == (n - 29,)
+    assert bool(torch.isfinite(feat).all()) and bool(torch.isfinite(p).all())
+    assert float((p.sum(1) - 1).abs().max()) < 1e-6
+    assert bool(((p[:, 1] > p[:, 0]).to(torch.uint8) == dec).all())
+    frac_speech = float(dec.float().mean())
+    assert 0.0 < frac_speech < 1.0
+    # determinism
+    p_first = p.clone()
+    feat_first = feat[:100000].clone()
+    vad.vad_stream(net, stream, n, workspace=ws)
+    assert torch.equal(p, p_first) and torch.equal(feat[:100000], feat_first)
+    # slice independence + oracle parity on spot slices (first, middle, last full, ragged tail)
+    host_rows = lambda lo, hi: stream[lo * 480: hi * 480].cpu().numpy().reshape(-1, 480)
+    n_slices = (n + 165) // 166
+    for s in (0, 36144, n_slices - 2, n_slices - 1):
+        lo, hi = 166 * s, min(166 * s + 166, n)
+        aligned = host_rows(lo, hi + 3)                       # padded-stream rows lo .. hi+2
+        mf, de = vad.mfcc_delta_slices(torch.from_numpy(aligned[None]).cuda())
+        assert torch.equal(mf[0], feat[lo:hi, :12]) and torch.equal(de[0], feat[lo:hi, 12:])
+        _, rm, rd = mfcc_ref.process_test_frames(aligned[3:], aligned[:3])
+        assert_feat_close(feat[lo:hi, :12].cpu().numpy(), rm, 'mfcc slice %d' % s)
+        assert_feat_close(feat[lo:hi, 12:].cpu().numpy(), rd, 'delta slice %d' % s)
+    # window independence: posteriors of scattered windows from a materialised (B,30,24) batch
+    idx = torch.tensor([0, 1, 31, 32, 255, 256, 4_000_000, 7_777_777, n - 31, n - 30], device='cuda')
+    batch = torch.stack([feat[i:i + 30] for i in idx.tolist()])
+    pb, _ = net.score(batch.contiguous())
+    assert torch.equal(pb, p[idx])
+    with torch.no_grad():
+        y = ref(batch.cpu()).numpy()
+    assert np.abs(pb.cpu().numpy() - y).max() <= 1e-5

@@ -164,8 +164,8 @@ def test_model_stack_names(vad):
 
 def test_end_to_end_stream(vad):
     """int16 audio -> features -> posteriors -> decisions against the float64/fp32 CPU path.
-    The front end's own tolerance (1e-4 relative on features) propagates into the posterior
-    here, so the end-to-end bar is 1e-4 absolute; model-only parity above holds 1e-5."""
+    Features carry the front end's own tolerance (1e-4 relative, floor 1.0); the posteriors still
+    hold the 1e-5 absolute bar end to end (measured margin: 4e-7, tools/accuracy_report.py)."""
     n = 1200
     ref = models_ref.make_model('gru_large')
     net = vad.Net(large=True, lstm=False)
@@ -177,5 +177,5 @@ def test_end_to_end_stream(vad):
     assert p.shape == (n - 29, 2)
     err_f = np.abs(feat.cpu().numpy() - feat_ref) / np.maximum(np.abs(feat_ref), 1.0)
     assert err_f.max() <= 1e-4
-    assert np.abs(p.cpu().numpy() - p_ref).max() <= 1e-4
-    _decisions_agree(dec.cpu().numpy(), p_ref, tol=1e-4)
+    assert np.abs(p.cpu().numpy() - p_ref).max() <= ATOL
+    _decisions_agree(dec.cpu().numpy(), p_ref)

@@ -1,0 +1,36 @@
+"""Accuracy margins of the HIP path against the CPU oracle on a longer synthetic sample (GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import voice_activity_detection_amd as pkg
+from oracle import models_ref, pipeline_ref, synth_ref
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
+host = synth_ref.synth_frames(0, n, seed=1337)
+stream = pkg.synth_stream(0, n, seed=1337)
+feat = pkg.mfcc_delta_stream(stream, n, 166).cpu().numpy().astype(np.float64)
+ref = pipeline_ref.features_sliced(host, 166).astype(np.float64)       # float32-stored oracle features
+err = np.abs(feat - ref) / np.maximum(np.abs(ref), 1.0)
+for name, sl in (('mfcc', slice(0, 12)), ('delta', slice(12, 24))):
+    e = err[:, sl]
+    print('%-5s scaled err: max %.3e  p99.9 %.3e  median %.3e   (|ref| max %.1f)'
+          % (name, e.max(), np.quantile(e, 0.999), np.median(e), np.abs(ref[:, sl]).max()))
+silent = (np.abs(host).max(1) == 0).astype(int)
+run5 = np.zeros(n, bool)                       # frame t and its 4 predecessors are all silent
+run5[4:] = np.convolve(silent, np.ones(5, int), 'valid') == 5
+print('frames whose whole analysis window is silent: %d of %d; max |mfcc| there: %.3e'
+      % (run5.sum(), n, np.abs(feat[run5][:, :12]).max() if run5.any() else 0.0))
+xw = pipeline_ref.windows(ref.astype(np.float32))
+for kind in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small', 'densenet', 'densenet_large'):
+    r = models_ref.make_model(kind)
+    net = pkg.DenseNet(large=kind.endswith('large')) if kind.startswith('densenet') else \
+        pkg.Net(large=kind.endswith('large'), lstm=kind.startswith('lstm'))
+    net.load_state_dict(r.state_dict())
+    y = pipeline_ref.score_windows(r, xw[:20000])
+    p_same, d_same = net.score(torch.from_numpy(ref[:20029].astype(np.float32)).cuda(), window_stride=24)
+    p_e2e, d_e2e = net.score(torch.from_numpy(feat[:20029].astype(np.float32)).cuda(), window_stride=24)
+    ref_dec = pipeline_ref.decide(y)
+    print('%-15s posterior err: same features max %.2e | own features max %.2e ; decisions differing %d / %d (same), %d (own)'
+          % (kind, np.abs(p_same.cpu().numpy() - y).max(), np.abs(p_e2e.cpu().numpy() - y).max(),
+             int((d_same.cpu().numpy() != ref_dec).sum()), len(y), int((d_e2e.cpu().numpy() != ref_dec).sum())))
