@@ -40,6 +40,13 @@ FRONTEND_BYTES_PER_FRAME = 480 * 2 + 24 * 4          # int16 in, 24 floats out
 FRONTEND_FLOP_PER_FRAME = 64_000                       # 2048-pt rfft + power + mel + DCT + delta
 PEAK_FP32_TFLOPS = 157.3                               # dense fp32 matrix = fp32 vector peak, MI355X
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per frame from rocprofv3 --pmc passes over this same command at 100 h (12,000,059 frames per launch;
+# profiles/r01_d_bench_pmc_100h.txt): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of 16-byte-per-lane
+# streaming reads at 64 bytes) + WRITE_SIZE, KiB -> bytes.  Counters cannot be read from inside this process, so the
+# per-launch figure is this measured per-frame constant times the frames of the launch.
+_KIB_PER_LAUNCH = {'frontend': 2 * (7129820 + 702017) + 750000 + 755859,      # mfcc_kernel + delta_kernel
+                   'gru_large': 2 * 633397 + 105469}                            # rnn_stream_kernel<GRU, large>
+TRAFFIC_BYTES_PER_FRAME = {k: v * 1024 / 12000059 for k, v in _KIB_PER_LAUNCH.items()}
 
 
 def make_models(kind):
@@ -175,14 +182,19 @@ def main():
         # Both kernels are bound by the SIMDs' fp32 FMA lanes: v_mfma_f32_32x32x2_f32 runs at the fp32 vector
         # rate and never co-executes with vector instructions (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/),
         # so fp32 MFMA and fp32 VALU share one 157.3 TFLOP/s peak.
+        nn_traffic = TRAFFIC_BYTES_PER_FRAME.get(args.model)
         model_roof = {'bound': 'mfma', 'kernel': 'model kernel (%s): rnn_stream_kernel / densenet_kernel' % args.model,
                       'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                      'frac': achieved / PEAK_FP32_TFLOPS, 'traffic': None, 'ms_per_launch': nn_ms,
+                      'frac': achieved / PEAK_FP32_TFLOPS,
+                      'traffic': None if nn_traffic is None else nn_traffic * n_windows, 'ms_per_launch': nn_ms,
+                      'algorithmic_bytes': (24 * 4 + 9) * n_windows,
                       'flop_per_window': FLOP_PER_WINDOW[args.model], 'windows_per_launch': n_windows,
                       'note': 'achieved = algorithmic (PyTorch-equivalent) flops / time; the stride-1 GRU/LSTM kernel '
                               'projects each feature row once instead of once per window, so it executes ~0.69x of them'}
         fe_roof = {'bound': 'mfma', 'kernel': 'mfcc_kernel (+ delta_kernel)', 'achieved': fe_tf, 'peak': PEAK_FP32_TFLOPS,
-                   'unit': 'TFLOP/s', 'frac': fe_tf / PEAK_FP32_TFLOPS, 'traffic': None, 'ms_per_launch': fe_ms,
+                   'unit': 'TFLOP/s', 'frac': fe_tf / PEAK_FP32_TFLOPS,
+                   'traffic': TRAFFIC_BYTES_PER_FRAME['frontend'] * n_frames, 'ms_per_launch': fe_ms,
+                   'algorithmic_bytes': FRONTEND_BYTES_PER_FRAME * n_frames,
                    'flop_per_frame': FRONTEND_FLOP_PER_FRAME, 'frames_per_launch': n_frames,
                    'pipe': 'fp32 vector ALU (same FMA lanes as fp32 MFMA)',
                    'hbm_GBs': fe_gbs, 'hbm_frac': fe_gbs / PEAK_HBM_GBS, 'bytes_per_frame': FRONTEND_BYTES_PER_FRAME}
