@@ -1,0 +1,43 @@
+// How many cycles does a SIMD spend per wave64 v_fma_f32 when 1, 2 or 4 waves share it?
+// One block per CU (100 KB of dynamic LDS keeps a second block out), block = 256 / 512 / 1024 threads.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+template <int MFMA>
+__global__ void probe(float* out, int iters, float a, float b) {
+    extern __shared__ float lds[];
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // inline asm keeps the compiler from pairing these into v_pk_fma_f32
+            asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+        }
+    }
+    if (iters < 0) lds[threadIdx.x] = x0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+
+int main() {
+    float* out;
+    hipMalloc(&out, 256 * 1024 * sizeof(float));
+    hipFuncSetAttribute((const void*)probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 20000;                       // 64 FMAs per iteration per wave
+    for (int threads : {256, 512, 1024}) {
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(probe<0>, dim3(256), dim3(threads), 100 * 1024, 0, out, iters, 1.0001f, 0.5f);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            double inst_per_simd = (double)iters * 64 * (threads / 256);
+            printf("waves/SIMD %d  %.3f ms  %.2f ns per wave-instruction per SIMD (x clock GHz = cycles)\n", threads / 256, ms,
+                   ms * 1e6 / inst_per_simd);
+        }
+    }
+    return 0;
+}

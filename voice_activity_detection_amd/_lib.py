@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvad_amd.so')
+# VAD_AMD_LIB selects another build of the same library (kernel experiments); the default is the in-tree one
+LIB_PATH = os.environ.get('VAD_AMD_LIB') or os.path.join(_HERE, 'libvad_amd.so')
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip']

@@ -17,9 +17,13 @@
 //   xchg 2  through LDS: lane (k1, q1) gathers the 16 points c
 //   pass C  radix-16 over c in registers
 //   result  lane 16 k1 + q1, register q2 holds Z[k1 + 4 q1 + 64 q2]
-// Z is stored transposed ([q2][lane], a linear image) and the real-input untangle works on the
-// pairs (k, 1024 - k), k < 512, that share Z[k] and Z[1024 - k]; the power spectrum is left in LDS
-// for the mel stage.
+// The real-input untangle works on the pairs (k, 1024 - k), k < 512, that share Z[k] and Z[1024 - k]:
+// the partner value is a register of another lane (ds_bpermute, no LDS image of Z); the power spectrum
+// is left in LDS for the mel stage.
+//
+// Occupancy is the design constraint: a wave stalls on its own LDS exchanges, so the kernel keeps three
+// waves per SIMD (<= 168 VGPRs, 49 KB of LDS per 4-wave block): the input is read straight from global
+// memory (no block staging buffer), two of the three twiddle sets live in a block-shared LDS table.
 //
 // Precision: FFT, power and mel sums in fp32; filter energies, log and DCT in
 // fp64 (26 logs and 312 fused multiply-adds per frame), because an fp32 log of
@@ -40,72 +44,85 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
-constexpr int kStageRows = kFramesPerBlock + 4;              // predecessor row + 16 frames + 3 trailing rows
-constexpr int kStageDwords = kStageRows * (kFrame / 2);       // int16 pairs
-constexpr int kSmemBytes = kStageDwords * 4 + kNFilt * kNCep * 8 + kWavesPerBlock * kWaveLdsBytes;
+constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twiddle tables
+constexpr int kSmemBytes = kWavesPerBlock * kWaveLdsBytes + kTwBytes;
+constexpr int kBlocksPerCu = 3;                              // = waves per SIMD; a block needs 49 KB of LDS
 
-// grid: blocks_per_slice blocks for each slice; a block owns 16 consecutive frames of ONE slice, so
-// its 20 input rows are contiguous whatever slice_stride is.  Wave w takes frames w, w+4, w+8, w+12.
-__global__ __launch_bounds__(256, 2) void mfcc_kernel(const int16_t* __restrict__ in, const MfccTables* __restrict__ tab,
-                                                      long n_slices, long frames_per_slice, long last_slice_frames,
-                                                      long slice_stride, int blocks_per_slice,
-                                                      float* __restrict__ out, long out_ld) {
+// Where frame g of the launch lives: slice s, frame j inside it.
+struct FramePos {
+    long s;
+    long j;
+};
+
+// grid: one block per 16 consecutive frames of the launch (slices are not padded to blocks: a block may
+// straddle slices, each frame finds its own slice).  Wave w takes frames w, w+4, w+8, w+12 of the block, so
+// the four waves walk neighbouring rows at the same time and the 4x re-read of every input row (hop 480,
+// window 1920, plus the pre-emphasis lag) is served by the caches.
+__global__ __launch_bounds__(256, kBlocksPerCu) void mfcc_kernel(const int16_t* __restrict__ in,
+                                                                 const MfccTables* __restrict__ tab, long n_frames,
+                                                                 long frames_per_slice, long slice_stride,
+                                                                 float* __restrict__ out, long out_ld) {
     __shared__ __align__(16) unsigned char smem[kSmemBytes];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    int* stage = reinterpret_cast<int*>(smem);
-    double* dct_s = reinterpret_cast<double*>(smem + kStageDwords * 4);
-    unsigned char* wbase = smem + kStageDwords * 4 + kNFilt * kNCep * 8 + wave * kWaveLdsBytes;
-    float2* ex = reinterpret_cast<float2*>(wbase);                          // exchange 1 / 2, then Zt[16][64]
-    float* pw = reinterpret_cast<float*>(wbase + kExBytes);                  // power spectrum
-    float* en = pw + kPowFloats;                                             // [4 frames][32]
+    unsigned char* wbase = smem + wave * kWaveLdsBytes;
+    float2* ex = reinterpret_cast<float2*>(wbase);                          // exchange 1 / 2, power spectrum
+    float* en = reinterpret_cast<float*>(wbase + kExBytes);                  // [4 frames][32]
 
-    const long s = blockIdx.x / blocks_per_slice;
-    const int j0 = (int)(blockIdx.x - s * blocks_per_slice) * kFramesPerBlock;
-    const long n_s = (s == n_slices - 1) ? last_slice_frames : frames_per_slice;
-    if (j0 >= n_s) return;                                                   // block-uniform
-
-    // ---- stage aligned rows j0-1 .. j0+18 of the slice (zeros outside it).  The row in front of a
-    // slice's first aligned row is staged as zeros, which leaves that row un-emphasised exactly as
-    // the reference's 2-D preemphasis does. ----
-    {
-        const int16_t* slice = in + s * slice_stride;
-        const long rows = n_s + VAD_ALIGN_FRAMES;
-        if ((reinterpret_cast<uintptr_t>(slice) & 15) == 0) {
-            const uint4* src = reinterpret_cast<const uint4*>(slice);
-            uint4* dst = reinterpret_cast<uint4*>(stage);
-            for (int i = threadIdx.x; i < kStageDwords / 4; i += 256) {
-                const int row = i / 60, c4 = i - row * 60;
-                const long ar = (long)j0 - 1 + row;
-                dst[i] = (ar >= 0 && ar < rows) ? src[ar * 60 + c4] : make_uint4(0, 0, 0, 0);
-            }
+    // block-uniform: slice and in-slice offset of the block's first frame
+    const long g0 = (long)blockIdx.x * kFramesPerBlock;
+    const long s0 = g0 / frames_per_slice;
+    const long r0 = g0 - s0 * frames_per_slice;
+    auto locate = [&](int jl) {                             // frame g0 + jl (wave-uniform)
+        FramePos p;
+        const long off = r0 + jl;
+        if (off < frames_per_slice) {
+            p.s = s0;
+            p.j = off;
+        } else if (frames_per_slice >= kFramesPerBlock) {   // at most one slice boundary inside a block
+            p.s = s0 + 1;
+            p.j = off - frames_per_slice;
         } else {
-            const int* src = reinterpret_cast<const int*>(slice);
-            for (int i = threadIdx.x; i < kStageDwords; i += 256) {
-                const int row = i / 240, c = i - row * 240;
-                const long ar = (long)j0 - 1 + row;
-                stage[i] = (ar >= 0 && ar < rows) ? src[ar * 240 + c] : 0;
-            }
+            const long ds = off / frames_per_slice;
+            p.s = s0 + ds;
+            p.j = off - ds * frames_per_slice;
         }
-    }
-    for (int i = threadIdx.x; i < kNFilt * kNCep; i += 256) dct_s[i] = (&tab->dct[0][0])[i];
+        return p;
+    };
+    // aligned row r of a slice = its frame r - 3; frame j reads rows j .. j+3 and their predecessors
+    // j-1 .. j+2 (row -1 does not exist: zero_first_pred).  Every slice holds its frames + 3 rows.
+    auto lane_ptr = [&](const FramePos& p) {
+        return reinterpret_cast<const int*>(in + p.s * slice_stride) + p.j * (kFrame / 2) + lane;
+    };
 
     LaneConst K;
     load_lane_const(K, tab, lane);
-    __syncthreads();
+    const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * kWaveLdsBytes);
+
+    RawFrame raw;
+    {
+        // tw1, tw2, twr are the first members of MfccTables, contiguous in this order
+        const float4* src = reinterpret_cast<const float4*>(tab);
+        float4* dst = reinterpret_cast<float4*>(smem + kWavesPerBlock * kWaveLdsBytes);
+        for (int i = threadIdx.x; i < kTwFloat2s / 2; i += 256) dst[i] = src[i];
+        __syncthreads();
+    }
 
     int nfr = 0;                                            // frames this wave produced (wave-uniform)
 #pragma unroll 1
     for (int it = 0; it < kFramesPerWave; ++it) {
-        const int jl = wave + it * kWavesPerBlock;          // frame index inside the block
-        if (j0 + jl >= n_s) break;
+        const int jl = wave + it * kWavesPerBlock;
+        if (g0 + jl >= n_frames) break;
         nfr = it + 1;
-        // frame jl covers staged rows jl+1 .. jl+4
-        frame_energies(stage + (jl + 1) * (kFrame / 2) + lane, false, K, ex, pw, en + it * 32, lane);
+        const FramePos p = locate(jl);
+        // (fetching the wave's next frame under the mel stage instead was measured slower: it costs
+        // 30 live registers and the third wave per SIMD already covers the load latency)
+        frame_load(raw, lane_ptr(p), p.j == 0, lane);
+        frame_energies(raw, tws, K, ex, en + it * 32, lane);
     }
-    cepstra_tail(en, reinterpret_cast<double*>(wbase), dct_s, nfr, lane, out, out_ld,
-                 s * frames_per_slice + j0 + wave, kWavesPerBlock);
+    cepstra_tail(en, reinterpret_cast<double*>(wbase), &tab->dct[0][0], nfr, lane, out, out_ld, g0 + wave,
+                 kWavesPerBlock);
 }
 
 // delta[g] = (-2 f[g-2] - f[g-1] + f[g+1] + 2 f[g+2]) / 10 with the slice's own edge rows
@@ -264,12 +281,10 @@ extern "C" int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, i
     VAD_HIP_CHECK(hipGetDevice(&dev));
     const long n_frames = (long)((n_slices - 1) * frames_per_slice + last_slice_frames);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long bps = (frames_per_slice + kFramesPerBlock - 1) / kFramesPerBlock;
-    const long blocks = bps * n_slices;
+    const long blocks = (n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many frames for one launch");
-    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(256), 0, st, frames_dev, g_tables[dev], (long)n_slices,
-                       (long)frames_per_slice, (long)last_slice_frames, (long)slice_stride, (int)bps, mfcc_dev,
-                       (long)mfcc_ld);
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(256), 0, st, frames_dev, g_tables[dev], n_frames,
+                       (long)frames_per_slice, (long)slice_stride, mfcc_dev, (long)mfcc_ld);
     VAD_HIP_CHECK(hipGetLastError());
     return launch_delta(mfcc_dev, mfcc_ld, n_frames, frames_per_slice, delta_dev, delta_ld, 0, n_frames, st);
 }

@@ -1,5 +1,4 @@
-// Device-side building blocks of the MFCC front end, shared by the stand-alone kernel (mfcc.hip)
-// and the fused front-end + recurrent-model kernel (fused.hip).
+// Device-side building blocks of the MFCC front end (kernel and launch code: mfcc.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,7 +18,7 @@ constexpr int kEx1Stride = 272;               // exchange 1: complex elements pe
 constexpr int kEx2Plane = 272;                // exchange 2: complex elements per k1 plane (16 rows of 17): the two
                                               // planes of a 32-lane half interleave on the 64 banks
 constexpr int kExBytes = 8704;                // = 4*272*8 >= (3*272 + 15*17 + 16)*8, >= 1024*8
-constexpr int kPowFloats = 1056;              // P[0..1024] plus slack for reads past a lane's run
+constexpr int kPowFloats = 1056;              // P[0..1024] plus slack for reads past a lane's run (kept inside the region)
 
 struct MfccTables {
     float2 tw1[12][64];      // [(k1-1)*4 + b][lane]  W1024^((lane + 64 b) * k1)
@@ -97,25 +96,28 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 
-// Per-wave LDS: [exchange / Zt / partial sums / log energies][power spectrum][filter energies of 4 frames]
-constexpr int kWaveLdsBytes = kExBytes + kPowFloats * 4 + kFramesPerWave * 32 * 4;
+// Per-wave LDS: [exchange 1 / 2, then power spectrum + partial sums, then log energies][filter energies of 4 frames]
+constexpr int kPartOffset = kPowFloats;        // float offset of the 2 x 64 mel partial sums inside the exchange region
+constexpr int kWaveLdsBytes = kExBytes + kFramesPerWave * 32 * 4;
+static_assert((kPartOffset + 128) * 4 <= kExBytes, "power spectrum + partial sums must fit the exchange region");
 
-// Loop-invariant per-lane constants (about 90 VGPRs).
+// Block-shared LDS image of the twiddle tables: tw1[12][64], tw2[15][16], twr[8][64] (the head of MfccTables).
+constexpr int kTw2Offset = 12 * 64;
+constexpr int kTwrOffset = kTw2Offset + 15 * 16;
+constexpr int kTwFloat2s = kTwrOffset + 8 * 64;
+
+// Loop-invariant per-lane constants that stay in registers (the twiddles do not: see frame_energies).
 struct LaneConst {
-    float2 tw1[12], tw2[15], twr[8];
+    float2 tw2[15];                           // W256^(c q1) of this lane's c: the one twiddle set that fits the registers
     int run_start, run_count;
     float run_inv, run_w0, run_f0;
     int rise_first, rise_n, fall_first, fall_n;
-    int k1l, q1l, plane, pd, kbase;
+    int k1l, q1l, plane, kbase;
 };
 
 __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* __restrict__ tab, int lane) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) K.tw1[k] = tab->tw1[k][lane];
-#pragma unroll
     for (int k = 0; k < 15; ++k) K.tw2[k] = tab->tw2[k][lane & 15];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) K.twr[j] = tab->twr[j][lane];
     K.run_start = tab->run_start[lane];
     K.run_count = tab->run_count[lane];
     const float b0 = (float)tab->run_b0[lane], b1 = (float)tab->run_b1[lane];
@@ -127,31 +129,49 @@ __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* 
     K.rise_n = tab->rise_n[fl];
     K.fall_first = tab->fall_first[fl];
     K.fall_n = tab->fall_n[fl];
-    // untangle partner of bin k = k1 + 4 q1 + 64 jj: Zt[(15 - jj + pd) & 15][plane]
+    // untangle partner of bin k = k1 + 4 q1 + 64 jj: register 15 - jj of lane `plane` (lane 0 pairs with itself)
     K.k1l = lane >> 4;
     K.q1l = lane & 15;
     K.plane = K.k1l ? 16 * (4 - K.k1l) + 15 - K.q1l : (K.q1l ? 16 - K.q1l : 0);
-    K.pd = (lane == 0) ? 1 : 0;
     K.kbase = K.k1l + 4 * K.q1l;
 }
 
-// One frame: `cur_p` points (in LDS) at this lane's first int16 pair of the frame's first row; rows are
-// contiguous, the row 240 dwords earlier is the pre-emphasis predecessor.  With zero_first_pred the
-// predecessor of the frame's FIRST row is taken as zero (first frame of a slice: that row is not
-// pre-emphasised, as in the reference's 2-D preemphasis); callers that stage a zero row there pass false.
-// Writes the 26 mel filter energies to en_slot[0..25].
-__device__ __forceinline__ void frame_energies(const int* cur_p, bool zero_first_pred, const LaneConst& K, float2* ex,
-                                               float* pw, float* en_slot, int lane) {
-    float* part_r = reinterpret_cast<float*>(ex);                           // aliases ex once Z is consumed
+// Raw input of one frame as this lane holds it: int16 pairs n = lane + 64 jj of the frame's four rows
+// (cur) and of the rows one frame earlier (prv, the pre-emphasis predecessors).
+struct RawFrame {
+    int cur[15], prv[15];
+};
+
+// `cur_p` points (in global memory) at this lane's first int16 pair of the frame's first row; the frame's
+// four rows are contiguous and the row 240 dwords earlier is the pre-emphasis predecessor.  With
+// zero_first_pred the predecessor of the frame's FIRST row is taken as zero and not read (first frame of a
+// slice: that row is not pre-emphasised, as in the reference's 2-D preemphasis).  Neighbouring frames
+// re-read the same rows; those hits are served by the CU's vector L1 / the L2.
+__device__ __forceinline__ void frame_load(RawFrame& raw, const int* __restrict__ cur_p, bool zero_first_pred, int lane) {
+#pragma unroll
+    for (int jj = 0; jj < 15; ++jj) {
+        raw.cur[jj] = cur_p[64 * jj];
+        raw.prv[jj] = 0;
+        if (!(jj < 4 && zero_first_pred && (lane + 64 * jj) < kFrame / 2)) raw.prv[jj] = cur_p[64 * jj - kFrame / 2];
+    }
+}
+
+// One frame from its raw input to the 26 mel filter energies in en_slot[0..25].
+// The twiddle factors are read from `tws`, a block-shared LDS image of the tables, where they are used
+// instead of living in ~70 registers: the kernel is latency-bound (in-order waves stalling on their own
+// LDS exchanges), three waves per SIMD need the register file, and reading them from global memory
+// instead makes the kernel texture-path-bound (measured 2.2x slower).
+__device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, const LaneConst& K, float2* ex,
+                                               float* en_slot, int lane) {
+    float* pw = reinterpret_cast<float*>(ex);                               // aliases ex once exchange 2 is read
+    float* part_r = pw + kPartOffset;
     float* part_f = part_r + 64;
 
-    // ---- load + pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj ----
+    // ---- pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj ----
     float2 v[16];
 #pragma unroll
     for (int jj = 0; jj < 15; ++jj) {
-        const int cur = cur_p[64 * jj];
-        int prv = cur_p[64 * jj - kFrame / 2];
-        if (jj < 4 && zero_first_pred && (lane + 64 * jj) < kFrame / 2) prv = 0;
+        const int cur = raw.cur[jj], prv = raw.prv[jj];
         const float x0 = fmaf(-0.97f, (float)(short)(prv & 0xFFFF), (float)(short)(cur & 0xFFFF));
         const float x1 = fmaf(-0.97f, (float)(prv >> 16), (float)(cur >> 16));
         v[jj] = make_float2(x0, x1);
@@ -162,7 +182,7 @@ __device__ __forceinline__ void frame_energies(const int* cur_p, bool zero_first
 #pragma unroll
     for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) v[4 + k] = cmul(v[4 + k], K.tw1[k]);
+    for (int k = 0; k < 12; ++k) v[4 + k] = cmul(v[4 + k], tws[k * 64 + lane]);
 
     // ---- exchange 1: [k1][n2 = lane + 64 b] -> lane (k1, c) reads n2 = c + 16 m ----
 #pragma unroll
@@ -198,30 +218,30 @@ __device__ __forceinline__ void frame_energies(const int* cur_p, bool zero_first
 
     // ---- pass C: radix 16 over c; register q2 now holds Z[k1 + 4 q1 + 64 q2] ----
     dft16(v);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) ex[64 * q + lane] = v[q];                 // Zt[q2][lane]
-    wave_lds_fence();
 
     // ---- real-input untangle on the pairs (k, 1024 - k), k = k1 + 4 q1 + 64 jj < 512:
     //      with E = Z[k] + conj(Z[N-k]), O = Z[k] - conj(Z[N-k]), T = W2048^k O,
-    //      4 |X[k]|^2 = |E - iT|^2 and 4 |X[N-k]|^2 = |E + iT|^2 ----
+    //      4 |X[k]|^2 = |E - iT|^2 and 4 |X[N-k]|^2 = |E + iT|^2.
+    //      Z[1024 - k] is register 15 - jj of lane `plane` (a cross-lane read, no LDS image of Z);
+    //      lane 0 holds the bins 64 q2, whose partners 64 (16 - q2) are its own registers. ----
+    const int paddr = K.plane * 4;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
-        const float2 a = ex[64 * jj + lane];
-        const float2 b = ex[64 * ((15 - jj + K.pd) & 15) + K.plane];
+        const float2 a = v[jj];
+        float2 b;
+        b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(v[15 - jj].x)));
+        b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(v[15 - jj].y)));
+        if (lane == 0) b = v[(16 - jj) & 15];
         const float2 e = make_float2(a.x + b.x, a.y - b.y);
         const float2 o = make_float2(a.x - b.x, a.y + b.y);
-        const float2 t = cmul(K.twr[jj], o);
+        const float2 t = cmul(tws[kTwrOffset + jj * 64 + lane], o);
         const float ar = e.x + t.y, ai = e.y - t.x;                       // E - iT
         const float br = e.x - t.y, bi = e.y + t.x;                       // E + iT
         const int k = K.kbase + 64 * jj;
         pw[k] = (ar * ar + ai * ai) * (0.25f / 2048.0f);
         pw[1024 - k] = (br * br + bi * bi) * (0.25f / 2048.0f);
     }
-    if (lane == 0) {                                                      // the self-paired bin 512
-        const float2 a = ex[64 * 8];
-        pw[512] = (a.x * a.x + a.y * a.y) * (1.0f / 2048.0f);
-    }
+    if (lane == 0) pw[512] = (v[8].x * v[8].x + v[8].y * v[8].y) * (1.0f / 2048.0f);   // the self-paired bin
     wave_lds_fence();
 
     // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the
@@ -235,7 +255,7 @@ __device__ __forceinline__ void frame_energies(const int* cur_p, bool zero_first
             sr = fmaf(p, fmaf((float)i, K.run_inv, K.run_w0), sr);
             sf = fmaf(p, fmaf(-(float)i, K.run_inv, K.run_f0), sf);
         }
-        part_r[lane] = sr;                                                // ex is free again (Z consumed)
+        part_r[lane] = sr;
         part_f[lane] = sf;
     }
     wave_lds_fence();
@@ -253,8 +273,9 @@ __device__ __forceinline__ void frame_energies(const int* cur_p, bool zero_first
 }
 
 // Tail for up to 4 frames of one wave at once: log of the 26 energies (fp64), lifted DCT-II (fp64).
-// Frame `it` goes to output row g0 + it * gstep.  `logv` may alias the exchange region.
-__device__ __forceinline__ void cepstra_tail(const float* en, double* logv, const double* dct_s, int nfr, int lane,
+// Frame `it` goes to output row g0 + it * gstep.  `logv` may alias the exchange region; `dct` is the
+// 26 x 12 table in global memory.
+__device__ __forceinline__ void cepstra_tail(const float* en, double* logv, const double* __restrict__ dct_s, int nfr, int lane,
                                              float* __restrict__ out, long out_ld, long g0, long gstep) {
 #pragma unroll
     for (int r = 0; r < kFramesPerWave / 2; ++r) {
