@@ -160,6 +160,21 @@ int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t wind
                              void* stream);
 
 /*
+ * Noise/speech mix ahead of the feature call on the training-data path: the
+ * int16 arithmetic of `noise_track.overlay(speech_track, gain_during_overlay=dB)`
+ * in add_noise (core/process_data.py:283-297; pydub -> audioop.mul + audioop.add):
+ *   out[i] = sat16( (apply_gain ? sat16(floor(noise[i] * gain_factor)) : noise[i]) + speech[i] ),  i < min(n_noise, n_speech)
+ *   out[i] = noise[i]                                                                             for the rest of the noise
+ * gain_factor = 10^(dB/20), computed by the caller in double precision as pydub
+ * does; a falsy gain (None, 0) in the reference means apply_gain = 0.
+ * noise_dev / speech_dev / out_dev: int16 device arrays of n_noise / n_speech /
+ * n_noise samples; out_dev may alias noise_dev.  16-byte aligned pointers take the
+ * wide path.
+ */
+int vad_overlay_i16(const int16_t* noise_dev, int64_t n_noise, const int16_t* speech_dev, int64_t n_speech,
+                    int apply_gain, double gain_factor, int16_t* out_dev, void* stream);
+
+/*
  * Deterministic synthetic 16 kHz int16 audio, written on the device: sample n
  * of stream `seed` is a pure integer function of (seed, n), reproducible on
  * the host.  No counterpart in the reference (its audio comes from datasets

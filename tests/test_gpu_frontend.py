@@ -45,6 +45,15 @@ def test_process_test_frames_matches_oracle(vad):
     assert_feat_close(d, rd, 'delta')
 
 
+def test_golden_slices(vad):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mfcc_slices.npz'))
+    mf, de = vad.mfcc_delta_slices(torch.from_numpy(g['rows']).cuda())
+    for s in range(g['rows'].shape[0]):
+        assert_feat_close(mf[s].cpu().numpy(), g['mfcc'][s], 'golden mfcc %d' % s)
+        assert_feat_close(de[s].cpu().numpy(), g['delta'][s], 'golden delta %d' % s)
+
+
 def test_zero_alignment_and_silence(vad):
     z = np.zeros((3, 480), np.int16)
     fr = synth_ref.synth_frames(0, 60, seed=5)

@@ -155,3 +155,15 @@ def test_decide():
     np.testing.assert_array_equal(pipeline_ref.decide(p), [0, 1, 0])
     np.testing.assert_array_equal(pipeline_ref.decide(p, 0.5), [1, 1, 0])
     np.testing.assert_array_equal(pipeline_ref.decide(p, 0.3), [1, 1, 1])
+
+
+def test_golden_slices_reproduce():
+    """The committed vectors (tests/golden/make_mfcc_fixtures.py) pin the restatement against regressions."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mfcc_slices.npz'))
+    for s in range(g['rows'].shape[0]):
+        _, m, d = mfcc_ref.process_test_frames(g['rows'][s, 3:], g['rows'][s, :3])
+        np.testing.assert_allclose(m, g['mfcc'][s], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(d, g['delta'][s], rtol=0, atol=1e-9)
+    # the zeroed frames of slice 1 put whole analysis windows into the eps clamp: cepstra vanish there
+    assert np.abs(g['mfcc'][1][23:28]).max() < 1e-9

@@ -8,12 +8,13 @@ GPU the calls raise ``VadError``.
 from ._lib import VadError, build, lib
 from .common import (ALIGN_FRAMES, BATCH_SIZE, FEATURES, FRAME_SIZE, FRAMES, SAMPLE_RATE, SLICE_MAX, STEP_SIZE)
 from .models import MODEL_STACK, DenseNet, Net
-from .process_data import (add_noise, mfcc_delta_slices, mfcc_delta_stream, overlay, process_test_frames)
+from .process_data import (add_noise, mfcc_delta_slices, mfcc_delta_stream, overlay, overlay_device,
+                           process_test_frames)
 from .stream import StreamWorkspace, vad_stream
 from .sharding import HALO_FRAMES, gather_posteriors, shard_plan, shard_range, window_owner_ranges
 from .synth import synth_audio, synth_stream
 
 __all__ = ['VadError', 'build', 'lib', 'Net', 'DenseNet', 'MODEL_STACK', 'process_test_frames', 'add_noise',
-           'overlay', 'mfcc_delta_slices', 'mfcc_delta_stream', 'vad_stream', 'StreamWorkspace', 'synth_audio',
+           'overlay', 'overlay_device', 'mfcc_delta_slices', 'mfcc_delta_stream', 'vad_stream', 'StreamWorkspace', 'synth_audio',
            'synth_stream', 'SAMPLE_RATE', 'FRAME_SIZE', 'FRAMES', 'FEATURES', 'BATCH_SIZE', 'SLICE_MAX',
            'ALIGN_FRAMES', 'STEP_SIZE']

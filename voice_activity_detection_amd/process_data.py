@@ -11,8 +11,9 @@ plus device-resident batch forms that the per-slice Python loop of
 
 * ``mfcc_delta_slices``  a batch of independently stored slices
 * ``mfcc_delta_stream``  one contiguous stream cut into fixed-length slices
+* ``overlay_device``     the int16 noise/speech mix of add_noise on device tensors
 
-All arithmetic runs in ``vad_mfcc_delta_f32`` of libvad_amd.so.
+All arithmetic runs in ``vad_mfcc_delta_f32`` / ``vad_overlay_i16`` of libvad_amd.so.
 """
 import ctypes
 
@@ -110,24 +111,54 @@ def process_test_frames(data_frames, align_frames):
     return frames, mfcc[0].cpu().numpy().astype(np.float64), delta[0].cpu().numpy().astype(np.float64)
 
 
-def overlay(noise_frames, speech_frames, gain_during_overlay=None):
-    """int16 mix standing in for ``noise_track.overlay(speech_track, gain_during_overlay=dB)``
-    (core/process_data.py:293).  PARITY UNPINNED: pydub/audioop are not available to check
-    against; restated as audioop.mul (scale, floor, saturate) on the noise followed by
-    audioop.add (saturating sum).  A falsy gain (None or 0) leaves the noise unscaled.
-    This is data synthesis ahead of the hot path and runs on the host.
+def overlay_device(noise_dev, speech_dev, gain_during_overlay=None, out=None):
+    """Device form of ``noise_track.overlay(speech_track, gain_during_overlay=dB)``
+    (core/process_data.py:293) on int16 CUDA tensors: the noise is scaled by 10^(dB/20)
+    (floor, saturate) over the overlaid part and the speech is added with saturation; noise
+    beyond the end of the speech is passed through.  A falsy gain (None or 0) leaves the
+    noise unscaled, as in pydub.  ``out`` may be the noise tensor itself.
     """
-    noise = _as_frames(noise_frames, 'noise_frames').astype(np.float64)
-    speech = _as_frames(speech_frames, 'speech_frames').astype(np.int64)
-    if gain_during_overlay:
-        noise = np.clip(np.floor(noise * (10.0 ** (gain_during_overlay / 20.0))), -32768, 32767)
-    n = min(noise.shape[0], speech.shape[0])
-    mixed = noise.astype(np.int64)
-    mixed[:n] = np.clip(mixed[:n] + speech[:n], -32768, 32767)
-    return mixed.astype(np.int16)
+    L = _lib.lib()
+    for name, t in (('noise_dev', noise_dev), ('speech_dev', speech_dev)):
+        if t.dtype != torch.int16 or not t.is_cuda or not t.is_contiguous():
+            raise ValueError('%s must be a contiguous int16 CUDA tensor' % name)
+    if out is None:
+        out = torch.empty_like(noise_dev)
+    elif out.dtype != torch.int16 or not out.is_cuda or not out.is_contiguous() or out.numel() != noise_dev.numel():
+        raise ValueError('out must be a contiguous int16 CUDA tensor of the size of noise_dev')
+    factor = 10.0 ** (float(gain_during_overlay) / 20.0) if gain_during_overlay else 1.0
+    with torch.cuda.device(noise_dev.device):
+        _lib.check(L.vad_overlay_i16(ctypes.c_void_p(noise_dev.data_ptr()), noise_dev.numel(),
+                                     ctypes.c_void_p(speech_dev.data_ptr()), speech_dev.numel(),
+                                     1 if gain_during_overlay else 0, factor,
+                                     ctypes.c_void_p(out.data_ptr()), _lib.current_stream()))
+    return out
+
+
+def overlay(noise_frames, speech_frames, gain_during_overlay=None):
+    """numpy in, numpy out wrapper of ``overlay_device``: (M,480) int16 mixed frames."""
+    noise = _as_frames(noise_frames, 'noise_frames')
+    speech = _as_frames(speech_frames, 'speech_frames')
+    dev = _device()
+    mixed = overlay_device(torch.from_numpy(noise).to(dev), torch.from_numpy(speech).to(dev), gain_during_overlay)
+    return mixed.cpu().numpy()
 
 
 def add_noise(speech_frames, noise_frames, align_frames, noise_level_db):
-    """Drop-in for core/process_data.py:282-309: mix, then the same MFCC/delta tail."""
-    frames = overlay(noise_frames, speech_frames, noise_level_db)
-    return process_test_frames(frames, align_frames)
+    """Drop-in for core/process_data.py:282-309: mix on the device, then the same MFCC/delta
+    tail, without the mixed audio leaving the device in between."""
+    noise = _as_frames(noise_frames, 'noise_frames')
+    speech = _as_frames(speech_frames, 'speech_frames')
+    align = _as_frames(align_frames, 'align_frames')
+    if len(align) != ALIGN_FRAMES:
+        raise ValueError('align_frames must hold %d frames' % ALIGN_FRAMES)
+    if len(noise) == 0:
+        raise ValueError('noise_frames is empty')
+    dev = _device()
+    aligned = torch.empty((1, len(noise) + ALIGN_FRAMES, FRAME_SIZE), dtype=torch.int16, device=dev)
+    aligned[0, :ALIGN_FRAMES] = torch.from_numpy(align).to(dev)
+    mixed = aligned[0, ALIGN_FRAMES:]                                    # contiguous view: rows 3.. of the slice
+    overlay_device(torch.from_numpy(noise).to(dev), torch.from_numpy(speech).to(dev), noise_level_db, out=mixed)
+    mfcc, delta = mfcc_delta_slices(aligned)
+    return (mixed.cpu().numpy(), mfcc[0].cpu().numpy().astype(np.float64),
+            delta[0].cpu().numpy().astype(np.float64))
