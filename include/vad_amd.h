@@ -175,6 +175,29 @@ int vad_overlay_i16(const int16_t* noise_dev, int64_t n_noise, const int16_t* sp
                     int apply_gain, double gain_factor, int16_t* out_dev, void* stream);
 
 /*
+ * Threshold sweep over posteriors: the consumer side of the path.  For an
+ * ascending table of thresholds t_0 < ... < t_{T-1} (T <= VAD_MAX_THRESHOLDS)
+ * one pass counts, per class, the scores with score >= t_k -- the confusion
+ * matrix of every threshold at once.  Replaces the per-candidate
+ * `apply_threshold` (y >= t) + `confusion_matrix` of the FAR-at-fixed-FRR search
+ * fix_frr (core/train.py:486-528), which rescans all scores for each t *= 1.1 step.
+ * The comparison is (double)score >= t_k, as numpy.float32 against a Python float
+ * evaluates in the reference; NaN scores are below every threshold.
+ *   score_dev       float32, element i at score_dev[i * score_stride] (stride 2 reads
+ *                   column 1 of an (n,2) posterior array in place)
+ *   label_dev       uint8, non-zero = speech
+ *   thresholds_dev  T doubles, ascending
+ *   hist_dev        scratch/out, 2*(T+1) uint64: [bin][class], bin = #thresholds <= score
+ *   ge_dev          out, T x 2 int64: [k][class] = scores of that class >= t_k
+ *                   (class 1: true positives, class 0: false positives at threshold k)
+ *   total_dev       out, 2 int64: scores per class
+ */
+#define VAD_MAX_THRESHOLDS 2048
+int vad_threshold_sweep_f32(const float* score_dev, int64_t score_stride, const uint8_t* label_dev, int64_t n,
+                            const double* thresholds_dev, int n_thresholds,
+                            unsigned long long* hist_dev, int64_t* ge_dev, int64_t* total_dev, void* stream);
+
+/*
  * Deterministic synthetic 16 kHz int16 audio, written on the device: sample n
  * of stream `seed` is a pure integer function of (seed, n), reproducible on
  * the host.  No counterpart in the reference (its audio comes from datasets

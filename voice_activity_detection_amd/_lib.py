@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAD_AMD_LIB') or os.path.join(_HERE, 'libvad_amd.so')
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
-SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip', 'overlay.hip']
+SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip', 'overlay.hip', 'sweep.hip']
 HEADERS = ['vad_internal.h', 'mfcc_device.h', 'rnn_device.h']
 
 # every symbol include/vad_amd.h declares
@@ -23,7 +23,7 @@ SYMBOLS = [
     'vad_net_blob_floats', 'vad_pack_net_weights',
     'vad_densenet_blob_floats', 'vad_densenet_tensor_count', 'vad_pack_densenet_weights',
     'vad_gru_forward_f32', 'vad_lstm_forward_f32', 'vad_densenet_forward_f32',
-    'vad_synth_audio_i16', 'vad_overlay_i16',
+    'vad_synth_audio_i16', 'vad_overlay_i16', 'vad_threshold_sweep_f32',
 ]
 
 
@@ -88,6 +88,8 @@ def lib():
     L.vad_synth_audio_i16.argtypes = [c_void, c_i64, c_i64, ctypes.c_uint32, c_void]
     L.vad_overlay_i16.restype = ctypes.c_int
     L.vad_overlay_i16.argtypes = [c_void, c_i64, c_void, c_i64, ctypes.c_int, ctypes.c_double, c_void, c_void]
+    L.vad_threshold_sweep_f32.restype = ctypes.c_int
+    L.vad_threshold_sweep_f32.argtypes = [c_void, c_i64, c_void, c_i64, c_void, ctypes.c_int, c_void, c_void, c_void, c_void]
     _lib = L
     return L
 
