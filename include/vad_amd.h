@@ -160,6 +160,25 @@ int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t wind
                              void* stream);
 
 /*
+ * Sampled windows: window w starts at feature row window_rows_dev[w] of a packed
+ * (n_rows, 24) matrix.  This is the access pattern of the reference's batch
+ * provider, DataGenerator.get_batch (core/generator.py:111-165), which draws
+ * class-balanced window starts at random and stacks mfcc[i:i+30] | delta[i:i+30]
+ * per start (:143-150) before test_predict scores the batch (core/train.py:416-440);
+ * here the batch tensor is never built.  Row indices outside 0 .. n_rows-30 are
+ * clamped into that range.  Other arguments as in the *_forward_f32 calls.
+ */
+int vad_gru_forward_rows_f32(const float* feat_dev, int64_t n_rows, const int64_t* window_rows_dev,
+                             int64_t n_windows, const float* blob_dev, int hidden, int large,
+                             float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold, void* stream);
+int vad_lstm_forward_rows_f32(const float* feat_dev, int64_t n_rows, const int64_t* window_rows_dev,
+                              int64_t n_windows, const float* blob_dev, int hidden, int large,
+                              float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold, void* stream);
+int vad_densenet_forward_rows_f32(const float* feat_dev, int64_t n_rows, const int64_t* window_rows_dev,
+                                  int64_t n_windows, const float* blob_dev, int large,
+                                  float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold, void* stream);
+
+/*
  * Noise/speech mix ahead of the feature call on the training-data path: the
  * int16 arithmetic of `noise_track.overlay(speech_track, gain_during_overlay=dB)`
  * in add_noise (core/process_data.py:283-297; pydub -> audioop.mul + audioop.add):

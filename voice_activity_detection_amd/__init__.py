@@ -11,6 +11,7 @@ from .models import MODEL_STACK, DenseNet, Net
 from .process_data import (add_noise, mfcc_delta_slices, mfcc_delta_stream, overlay, overlay_device,
                            process_test_frames)
 from . import metrics
+from .generator import DataGenerator
 from .metrics import fix_frr, roc_curve, threshold_sweep
 from .stream import StreamWorkspace, vad_stream
 from .sharding import HALO_FRAMES, gather_posteriors, shard_plan, shard_range, window_owner_ranges
@@ -18,6 +19,6 @@ from .synth import synth_audio, synth_stream
 
 __all__ = ['VadError', 'build', 'lib', 'Net', 'DenseNet', 'MODEL_STACK', 'process_test_frames', 'add_noise',
            'overlay', 'overlay_device', 'mfcc_delta_slices', 'mfcc_delta_stream', 'vad_stream', 'StreamWorkspace',
-           'synth_audio', 'metrics', 'fix_frr', 'roc_curve', 'threshold_sweep',
+           'synth_audio', 'metrics', 'DataGenerator', 'fix_frr', 'roc_curve', 'threshold_sweep',
            'synth_stream', 'SAMPLE_RATE', 'FRAME_SIZE', 'FRAMES', 'FEATURES', 'BATCH_SIZE', 'SLICE_MAX',
            'ALIGN_FRAMES', 'STEP_SIZE']

@@ -142,7 +142,7 @@ __device__ __forceinline__ void dense_block(float* act, const float* __restrict_
 }
 
 template <bool LARGE>
-__global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ x, long n_windows, long wstride,
+__global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ x, long n_windows, WindowMap wm,
                                                       const float* __restrict__ blob, float* __restrict__ p_out,
                                                       uint8_t* __restrict__ dec_out, int mode, float threshold) {
     using D = Dims<LARGE>;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
     const int col = lane & 31;
     const long w = (long)blockIdx.x * 32 + col;
     const long wc = w < n_windows ? w : n_windows - 1;
-    const float* xw = x + wc * wstride + 12 * half;
+    const float* xw = window_ptr(x, wm, wc) + 12 * half;
 
     // ---- stem: Conv1d(24 -> c0, k = 6, dilation 4) + BN + MaxPool(2) + LeakyReLU, 30 -> 10 -> 5 ----
     for (int lp = 0; lp < kL1; ++lp) {
@@ -343,11 +343,11 @@ int pack(const float* const* t, float* blob) {
 }
 
 template <bool LARGE>
-int launch(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
+int launch(const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec, int mode,
            float threshold, hipStream_t st) {
     const long blocks = (n_windows + 31) / 32;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
-    hipLaunchKernelGGL(densenet_kernel<LARGE>, dim3((unsigned)blocks), dim3(64), 0, st, x, n_windows, wstride, blob, p,
+    hipLaunchKernelGGL(densenet_kernel<LARGE>, dim3((unsigned)blocks), dim3(64), 0, st, x, n_windows, wm, blob, p,
                        dec, mode, threshold);
     VAD_HIP_CHECK(hipGetLastError());
     return VAD_OK;
@@ -374,19 +374,38 @@ extern "C" int vad_pack_densenet_weights(int large, const float* const* tensors_
     return large ? pack<true>(tensors_host, blob_host) : pack<false>(tensors_host, blob_host);
 }
 
-extern "C" int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
-                                        const float* blob_dev, int large, float* p_dev, uint8_t* decision_dev,
-                                        int decision_mode, float threshold, void* stream) {
-    using namespace vad;
+namespace vad {
+namespace {
+int densenet_forward(const float* x_dev, int64_t n_windows, WindowMap wm, const float* blob_dev, int large, float* p_dev,
+                     uint8_t* decision_dev, int decision_mode, float threshold, void* stream) {
     VAD_REQUIRE(x_dev && blob_dev && p_dev, "null pointer argument");
     VAD_REQUIRE(n_windows >= 0, "n_windows must be >= 0");
-    VAD_REQUIRE(window_stride >= 0 && (window_stride % 4) == 0, "window_stride must be a non-negative multiple of 4 floats");
+    VAD_REQUIRE(wm.stride >= 0 && (wm.stride % 4) == 0, "window_stride must be a non-negative multiple of 4 floats");
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0, "x_dev must be 16-byte aligned");
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(p_dev) & 7) == 0, "p_dev must be 8-byte aligned");
     VAD_REQUIRE(decision_mode == VAD_DECIDE_ARGMAX || decision_mode == VAD_DECIDE_THRESHOLD, "unknown decision_mode %d",
                 decision_mode);
     if (n_windows == 0) return VAD_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    return large ? launch<true>(x_dev, n_windows, window_stride, blob_dev, p_dev, decision_dev, decision_mode, threshold, st)
-                 : launch<false>(x_dev, n_windows, window_stride, blob_dev, p_dev, decision_dev, decision_mode, threshold, st);
+    return large ? launch<true>(x_dev, n_windows, wm, blob_dev, p_dev, decision_dev, decision_mode, threshold, st)
+                 : launch<false>(x_dev, n_windows, wm, blob_dev, p_dev, decision_dev, decision_mode, threshold, st);
+}
+}  // namespace
+}  // namespace vad
+
+extern "C" int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                                        const float* blob_dev, int large, float* p_dev, uint8_t* decision_dev,
+                                        int decision_mode, float threshold, void* stream) {
+    return vad::densenet_forward(x_dev, n_windows, vad::WindowMap{(long)window_stride, nullptr, 0}, blob_dev, large, p_dev,
+                                 decision_dev, decision_mode, threshold, stream);
+}
+
+extern "C" int vad_densenet_forward_rows_f32(const float* feat_dev, int64_t n_rows, const int64_t* window_rows_dev,
+                                             int64_t n_windows, const float* blob_dev, int large, float* p_dev,
+                                             uint8_t* decision_dev, int decision_mode, float threshold, void* stream) {
+    vad::WindowMap wm;
+    const int rc = vad::window_map_for_rows(n_rows, window_rows_dev, n_windows, &wm);
+    if (rc != VAD_OK) return rc;
+    return vad::densenet_forward(feat_dev, n_windows, wm, blob_dev, large, p_dev, decision_dev, decision_mode, threshold,
+                                 stream);
 }

@@ -50,7 +50,7 @@ namespace {
 // any window stride
 
 template <bool LSTM, bool LARGE, int KS>
-__global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x, long n_windows, long wstride,
+__global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x, long n_windows, WindowMap wm,
                                                      const float* __restrict__ blob, float* __restrict__ p_out,
                                                      uint8_t* __restrict__ dec_out, int mode, float threshold) {
     constexpr int G = LSTM ? 4 : 3;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x
     const long w = tile * kWindowsPerWave + col;
     if (tile * kWindowsPerWave >= n_windows) return;            // wave-uniform
     const long wc = w < n_windows ? w : n_windows - 1;          // clamp loads, mask the store
-    const float* xw = x + wc * wstride + 12 * half;
+    const float* xw = window_ptr(x, wm, wc) + 12 * half;
 
     f32x16 h, c, lacc;
 #pragma unroll
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
 // see the whole previous state as B operand, so the new state is double-buffered in registers.
 
 template <bool LARGE, int UT>
-__global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restrict__ x, long n_windows, long wstride,
+__global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restrict__ x, long n_windows, WindowMap wm,
                                                           const float* __restrict__ blob, float* __restrict__ p_out,
                                                           uint8_t* __restrict__ dec_out, int mode, float threshold) {
     extern __shared__ __align__(16) float lds[];
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restric
     const long w = tile * kWindowsPerWave + col;
     if (tile * kWindowsPerWave >= n_windows) return;
     const long wc = w < n_windows ? w : n_windows - 1;
-    const float* xw = x + wc * wstride + 12 * half;
+    const float* xw = window_ptr(x, wm, wc) + 12 * half;
 
     f32x16 h[UT], hn[UT], lacc;
 #pragma unroll
@@ -316,7 +316,7 @@ int ensure_rnn_attrs() {
 namespace {
 
 template <bool LARGE, int UT>
-int launch_wide(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
+int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec, int mode,
                 float threshold, hipStream_t st) {
     const NetLayout L = net_layout(false, LARGE, UT);
     const size_t lds_bytes = (size_t)L.head * sizeof(float);
@@ -326,7 +326,7 @@ int launch_wide(const float* x, long n_windows, long wstride, const float* blob,
     const long blocks = (n_windows + per_block - 1) / per_block;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
     hipLaunchKernelGGL((gru_wide_kernel<LARGE, UT>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds_bytes, st, x,
-                       n_windows, wstride, blob, p, dec, mode, threshold);
+                       n_windows, wm, blob, p, dec, mode, threshold);
     VAD_HIP_CHECK(hipGetLastError());
     return VAD_OK;
 }
@@ -335,9 +335,9 @@ int launch_wide(const float* x, long n_windows, long wstride, const float* blob,
 // launchers
 
 template <bool LSTM, bool LARGE, int KS>
-int launch_ks(const float* x, long n_windows, long wstride, const float* blob, float* p, uint8_t* dec, int mode,
+int launch_ks(const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec, int mode,
            float threshold, hipStream_t st) {
-    if (wstride == kF) {
+    if (!wm.rows && wm.stride == kF) {
         using C = StreamCfg<LSTM>;
         int rc = ensure_rnn_attrs();
         if (rc != VAD_OK) return rc;
@@ -355,21 +355,24 @@ int launch_ks(const float* x, long n_windows, long wstride, const float* blob, f
     const long blocks = (n_windows + per_block - 1) / per_block;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
     hipLaunchKernelGGL((rnn_kernel<LSTM, LARGE, KS>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds_bytes, st, x,
-                       n_windows, wstride, blob, p, dec, mode, threshold);
+                       n_windows, wm, blob, p, dec, mode, threshold);
     VAD_HIP_CHECK(hipGetLastError());
     return VAD_OK;
 }
 
 template <bool LSTM, bool LARGE>
-int launch(const float* x, long n_windows, long wstride, const float* blob, int hidden, float* p, uint8_t* dec, int mode,
+int launch(const float* x, long n_windows, WindowMap wm, const float* blob, int hidden, float* p, uint8_t* dec, int mode,
            float threshold, hipStream_t st) {
     return hidden_k_steps(hidden) == kHk - 1
-               ? launch_ks<LSTM, LARGE, kHk - 1>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
-               : launch_ks<LSTM, LARGE, kHk>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
+               ? launch_ks<LSTM, LARGE, kHk - 1>(x, n_windows, wm, blob, p, dec, mode, threshold, st)
+               : launch_ks<LSTM, LARGE, kHk>(x, n_windows, wm, blob, p, dec, mode, threshold, st);
 }
 
-int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const float* blob, int hidden, int large,
-            float* p, uint8_t* dec, int mode, float threshold, void* stream) {
+}  // namespace
+
+int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, const float* blob, int hidden, int large,
+                float* p, uint8_t* dec, int mode, float threshold, void* stream) {
+    const long wstride = wm.stride;
     VAD_REQUIRE(x && blob && p, "null pointer argument");
     VAD_REQUIRE(hidden >= 1 && hidden <= (lstm ? kHp : 3 * kHp),
                 "hidden must be in 1..32 (LSTM) or 1..96 (GRU), got %d", hidden);
@@ -382,20 +385,18 @@ int forward(bool lstm, const float* x, int64_t n_windows, int64_t wstride, const
     if (n_windows == 0) return VAD_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (lstm) {
-        return large ? launch<true, true>(x, n_windows, wstride, blob, hidden, p, dec, mode, threshold, st)
-                     : launch<true, false>(x, n_windows, wstride, blob, hidden, p, dec, mode, threshold, st);
+        return large ? launch<true, true>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st)
+                     : launch<true, false>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st);
     }
     if (hidden > 2 * kHp)
-        return large ? launch_wide<true, 3>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
-                     : launch_wide<false, 3>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
+        return large ? launch_wide<true, 3>(x, n_windows, wm, blob, p, dec, mode, threshold, st)
+                     : launch_wide<false, 3>(x, n_windows, wm, blob, p, dec, mode, threshold, st);
     if (hidden > kHp)
-        return large ? launch_wide<true, 2>(x, n_windows, wstride, blob, p, dec, mode, threshold, st)
-                     : launch_wide<false, 2>(x, n_windows, wstride, blob, p, dec, mode, threshold, st);
-    return large ? launch<false, true>(x, n_windows, wstride, blob, hidden, p, dec, mode, threshold, st)
-                 : launch<false, false>(x, n_windows, wstride, blob, hidden, p, dec, mode, threshold, st);
+        return large ? launch_wide<true, 2>(x, n_windows, wm, blob, p, dec, mode, threshold, st)
+                     : launch_wide<false, 2>(x, n_windows, wm, blob, p, dec, mode, threshold, st);
+    return large ? launch<false, true>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st)
+                 : launch<false, false>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st);
 }
-
-}  // namespace
 
 }  // namespace vad
 
@@ -486,13 +487,43 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
 extern "C" int vad_gru_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,
                                    int hidden, int large, float* p_dev, uint8_t* decision_dev, int decision_mode,
                                    float threshold, void* stream) {
-    return vad::forward(false, x_dev, n_windows, window_stride, blob_dev, hidden, large, p_dev, decision_dev,
-                        decision_mode, threshold, stream);
+    return vad::rnn_forward(false, x_dev, n_windows, vad::WindowMap{(long)window_stride, nullptr, 0}, blob_dev, hidden,
+                            large, p_dev, decision_dev, decision_mode, threshold, stream);
 }
 
 extern "C" int vad_lstm_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,
                                     int hidden, int large, float* p_dev, uint8_t* decision_dev, int decision_mode,
                                     float threshold, void* stream) {
-    return vad::forward(true, x_dev, n_windows, window_stride, blob_dev, hidden, large, p_dev, decision_dev,
-                        decision_mode, threshold, stream);
+    return vad::rnn_forward(true, x_dev, n_windows, vad::WindowMap{(long)window_stride, nullptr, 0}, blob_dev, hidden,
+                            large, p_dev, decision_dev, decision_mode, threshold, stream);
+}
+
+namespace vad {
+int window_map_for_rows(int64_t n_rows, const int64_t* window_rows_dev, int64_t n_windows, WindowMap* wm) {
+    VAD_REQUIRE(n_rows >= VAD_FRAMES, "the feature matrix needs at least %d rows, got %ld", VAD_FRAMES, (long)n_rows);
+    VAD_REQUIRE(window_rows_dev || n_windows == 0, "null pointer argument");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(window_rows_dev) & 7) == 0, "window_rows_dev must be 8-byte aligned");
+    *wm = WindowMap{VAD_FEATURES, window_rows_dev, (long)n_rows - VAD_FRAMES};
+    return VAD_OK;
+}
+}  // namespace vad
+
+extern "C" int vad_gru_forward_rows_f32(const float* feat_dev, int64_t n_rows, const int64_t* window_rows_dev,
+                                        int64_t n_windows, const float* blob_dev, int hidden, int large, float* p_dev,
+                                        uint8_t* decision_dev, int decision_mode, float threshold, void* stream) {
+    vad::WindowMap wm;
+    const int rc = vad::window_map_for_rows(n_rows, window_rows_dev, n_windows, &wm);
+    if (rc != VAD_OK) return rc;
+    return vad::rnn_forward(false, feat_dev, n_windows, wm, blob_dev, hidden, large, p_dev, decision_dev, decision_mode,
+                            threshold, stream);
+}
+
+extern "C" int vad_lstm_forward_rows_f32(const float* feat_dev, int64_t n_rows, const int64_t* window_rows_dev,
+                                         int64_t n_windows, const float* blob_dev, int hidden, int large, float* p_dev,
+                                         uint8_t* decision_dev, int decision_mode, float threshold, void* stream) {
+    vad::WindowMap wm;
+    const int rc = vad::window_map_for_rows(n_rows, window_rows_dev, n_windows, &wm);
+    if (rc != VAD_OK) return rc;
+    return vad::rnn_forward(true, feat_dev, n_windows, wm, blob_dev, hidden, large, p_dev, decision_dev, decision_mode,
+                            threshold, stream);
 }

@@ -40,6 +40,28 @@ int launch_delta(const float* mfcc_dev, long mfcc_ld, long n_frames, long frames
 // One-time per-device opt-in of the model kernels that need more than 64 KB of LDS; defined in rnn.hip.
 int ensure_rnn_attrs();
 
+// Where the windows of a model launch start.  rows == nullptr: window w starts at x + w * stride floats
+// (stride 24 = stride-1 windows of a packed feature matrix, 720 = dense (B,30,24) batch).  Otherwise window w
+// starts at feature row rows[w] of a packed (n_rows, 24) matrix (sampled windows); a row index outside
+// 0 .. last_start is clamped so that a bad index cannot make the kernel read outside the matrix.
+struct WindowMap {
+    long stride;
+    const int64_t* rows;
+    long last_start;
+};
+
+__device__ __forceinline__ const float* window_ptr(const float* x, const WindowMap& m, long w) {
+    if (m.rows) {
+        long r = (long)m.rows[w];
+        r = r < 0 ? 0 : (r > m.last_start ? m.last_start : r);
+        return x + r * VAD_FEATURES;
+    }
+    return x + w * m.stride;
+}
+
+// Validates the arguments of the *_rows_f32 entry points and builds their map; defined in rnn.hip.
+int window_map_for_rows(int64_t n_rows, const int64_t* window_rows_dev, int64_t n_windows, WindowMap* wm);
+
 // 32x32 MFMA accumulator geometry (v_mfma_f32_32x32x2_f32): register i of a
 // lane in half hh (= lane >> 5) holds row (i & 3) + 8 * (i >> 2) + 4 * hh of
 // the 32-row tile; the column is lane & 31.

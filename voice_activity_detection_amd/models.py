@@ -92,6 +92,35 @@ class _HipModule(nn.Module):
                                     _lib.current_stream()))
         return p, d
 
+    def score_rows(self, feat, window_rows, threshold=None, out=None, decisions=None):
+        """Posteriors of sampled windows: window w covers rows ``window_rows[w] .. +29`` of the packed
+        (F,24) float32 CUDA feature matrix ``feat`` -- the windows DataGenerator.get_batch stacks into
+        a batch (core/generator.py:143-150) -- without building the (B,30,24) tensor.
+        ``window_rows`` is an int64 CUDA tensor or any integer sequence."""
+        L = _lib.lib()
+        if not feat.is_cuda or feat.dtype != torch.float32 or not feat.is_contiguous() or feat.dim() != 2 \
+                or feat.size(1) != FEATURES:
+            raise ValueError('feat must be a contiguous float32 CUDA tensor of shape (F,%d)' % FEATURES)
+        if feat.size(0) < FRAMES:
+            raise ValueError('feat holds %d rows, a window needs %d' % (feat.size(0), FRAMES))
+        rows = torch.as_tensor(window_rows, dtype=torch.int64).to(feat.device).reshape(-1).contiguous()
+        n = rows.numel()
+        if n and (int(rows.min()) < 0 or int(rows.max()) > feat.size(0) - FRAMES):
+            raise IndexError('window start out of range 0..%d' % (feat.size(0) - FRAMES))
+        p = out if out is not None else torch.empty((n, 2), dtype=torch.float32, device=feat.device)
+        d = decisions if decisions is not None else torch.empty((n,), dtype=torch.uint8, device=feat.device)
+        if n == 0:
+            return p, d
+        blob = self._weights_on(feat.device)
+        mode = DECIDE_ARGMAX if threshold is None else DECIDE_THRESHOLD
+        with torch.cuda.device(feat.device):
+            _lib.check(self._launch_rows(L, ctypes.c_void_p(feat.data_ptr()), feat.size(0),
+                                         ctypes.c_void_p(rows.data_ptr()), n, ctypes.c_void_p(blob.data_ptr()),
+                                         ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(d.data_ptr()), mode,
+                                         ctypes.c_float(0.0 if threshold is None else threshold),
+                                         _lib.current_stream()))
+        return p, d
+
     def forward(self, x):
         # core/models.py:44-47 widens 1-D / 2-D inputs to a batch of length-1 sequences; the
         # reference's own view(-1, 900) then only works for 30-step windows, which is all it is fed.
@@ -138,6 +167,11 @@ class Net(_HipModule):
     def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
         fn = L.vad_lstm_forward_f32 if self.lstm else L.vad_gru_forward_f32
         return fn(x_ptr, n, stride, blob_ptr, self.rnn.hidden_size, int(self.large), p_ptr, d_ptr, mode, thr, stream)
+
+    def _launch_rows(self, L, f_ptr, n_rows, r_ptr, n, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+        fn = L.vad_lstm_forward_rows_f32 if self.lstm else L.vad_gru_forward_rows_f32
+        return fn(f_ptr, n_rows, r_ptr, n, blob_ptr, self.rnn.hidden_size, int(self.large), p_ptr, d_ptr, mode, thr,
+                  stream)
 
 
 class _DenseSingle(nn.Module):                 # parameter container, core/models.py:333-348
@@ -200,6 +234,10 @@ class DenseNet(_HipModule):
 
     def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
         return L.vad_densenet_forward_f32(x_ptr, n, stride, blob_ptr, int(self.large), p_ptr, d_ptr, mode, thr, stream)
+
+    def _launch_rows(self, L, f_ptr, n_rows, r_ptr, n, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+        return L.vad_densenet_forward_rows_f32(f_ptr, n_rows, r_ptr, n, blob_ptr, int(self.large), p_ptr, d_ptr, mode,
+                                               thr, stream)
 
 
 def _model_stack():
