@@ -81,3 +81,48 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libvad_amd.so')
     with pytest.raises(pkg.VadError):
         _lib.lib()
+
+
+def test_argument_checks_reject_before_any_device_work(L):
+    """Every compute entry point validates its arguments first and answers VAD_EINVAL (-1) with a message;
+    these calls never reach the HIP runtime, so they run on a GPU-less host."""
+    import ctypes
+    buf = np.zeros(64, np.float32)
+    ok = buf.ctypes.data_as(ctypes.c_void_p)                 # 16-byte aligned by numpy
+    odd = ctypes.c_void_p(buf.ctypes.data + 2)
+    f0 = ctypes.c_float(0.0)
+    cases = [
+        ('vad_mfcc_delta_f32', (None, 1, 1, 1, 480, ok, 12, ok, 12, None), b'null pointer'),
+        ('vad_mfcc_delta_f32', (ok, 0, 1, 1, 480, ok, 12, ok, 12, None), b'n_slices'),
+        ('vad_mfcc_delta_f32', (ok, 1, 4, 5, 480, ok, 12, ok, 12, None), b'last_slice_frames'),
+        ('vad_mfcc_delta_f32', (ok, 1, 1, 1, 481, ok, 12, ok, 12, None), b'slice_stride'),
+        ('vad_mfcc_delta_f32', (ok, 1, 1, 1, 480, ok, 11, ok, 12, None), b'leading dimensions'),
+        ('vad_mfcc_delta_f32', (odd, 1, 1, 1, 480, ok, 12, ok, 12, None), b'4-byte aligned'),
+        ('vad_gru_forward_f32', (None, 1, 720, ok, 30, 1, ok, None, 0, f0, None), b'null pointer'),
+        ('vad_gru_forward_f32', (ok, 1, 720, ok, 97, 1, ok, None, 0, f0, None), b'hidden'),
+        ('vad_lstm_forward_f32', (ok, 1, 720, ok, 33, 1, ok, None, 0, f0, None), b'hidden'),
+        ('vad_gru_forward_f32', (ok, -1, 720, ok, 30, 1, ok, None, 0, f0, None), b'n_windows'),
+        ('vad_gru_forward_f32', (ok, 1, 722, ok, 30, 1, ok, None, 0, f0, None), b'window_stride'),
+        ('vad_gru_forward_f32', (odd, 1, 720, ok, 30, 1, ok, None, 0, f0, None), b'16-byte aligned'),
+        ('vad_gru_forward_f32', (ok, 1, 720, ok, 30, 1, ok, None, 7, f0, None), b'decision_mode'),
+        ('vad_densenet_forward_f32', (ok, 1, 720, None, 0, ok, None, 0, f0, None), b'null pointer'),
+        ('vad_densenet_forward_f32', (ok, 1, 721, ok, 0, ok, None, 0, f0, None), b'window_stride'),
+        ('vad_gru_forward_rows_f32', (ok, 29, ok, 1, ok, 30, 1, ok, None, 0, f0, None), b'at least 30 rows'),
+        ('vad_lstm_forward_rows_f32', (ok, 100, None, 1, ok, 30, 1, ok, None, 0, f0, None), b'null pointer'),
+        ('vad_densenet_forward_rows_f32', (ok, 10, ok, 1, ok, 0, ok, None, 0, f0, None), b'at least 30 rows'),
+        ('vad_overlay_i16', (ok, -1, ok, 1, 0, 1.0, ok, None), b'negative'),
+        ('vad_overlay_i16', (None, 8, ok, 8, 0, 1.0, ok, None), b'null pointer'),
+        ('vad_overlay_i16', (ok, 8, ok, 8, 1, float('nan'), ok, None), b'gain factor'),
+        ('vad_threshold_sweep_f32', (ok, 1, ok, 8, ok, 0, ok, ok, ok, None), b'n_thresholds'),
+        ('vad_threshold_sweep_f32', (ok, 1, ok, 8, ok, 5000, ok, ok, ok, None), b'n_thresholds'),
+        ('vad_threshold_sweep_f32', (ok, 0, ok, 8, ok, 4, ok, ok, ok, None), b'score_stride'),
+        ('vad_threshold_sweep_f32', (None, 1, ok, 8, ok, 4, ok, ok, ok, None), b'null pointer'),
+        ('vad_synth_audio_i16', (None, 0, 8, 1, None), b'null pointer'),
+        ('vad_synth_audio_i16', (ok, -1, 8, 1, None), b'negative'),
+    ]
+    for name, args, needle in cases:
+        rc = getattr(L, name)(*args)
+        assert rc == -1, (name, args, rc)
+        assert needle in L.vad_last_error(), (name, L.vad_last_error())
+    assert L.vad_net_blob_floats(1, 1, 33) == 0 and L.vad_net_blob_floats(0, 1, 97) == 0
+    assert L.vad_net_blob_floats(0, 1, 30) > 0 and L.vad_densenet_blob_floats(1) > L.vad_densenet_blob_floats(0)

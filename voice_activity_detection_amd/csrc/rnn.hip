@@ -38,6 +38,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "rnn_device.h"
 
 namespace vad {
@@ -291,10 +293,12 @@ int allow_lds(K kernel, int floats) {
 
 // Kernels that use more than 64 KB of dynamic LDS must be opted in once per device.
 int ensure_rnn_attrs() {
+    static std::mutex mu;                       // callers on different host threads may race to the first launch
     static bool done[64] = {false};
     int dev = 0;
     VAD_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) return VAD_OK;
+    VAD_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
     if (done[dev]) return VAD_OK;
     int rc = VAD_OK;
     if ((rc = allow_lds(&rnn_stream_kernel<false, false, 15>, StreamCfg<false>::lds_floats))) return rc;
