@@ -97,6 +97,8 @@ def main():
     ap.add_argument('--model', default='gru_large', choices=sorted(FLOP_PER_WINDOW))
     ap.add_argument('--slice', type=int, default=166, help='frames per MFCC slice (reference test path: 166)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--matrix-mode', default='f32', choices=['f32', 'bf16x6', 'bf16x9'],
+                    help='how the stride-1 GRU/LSTM kernels form float32 products (default: float32 MFMA)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -123,6 +125,7 @@ def main():
     import voice_activity_detection_amd as pkg
     from voice_activity_detection_amd.sharding import shard_plan
     pkg.lib()
+    pkg.set_matrix_mode(args.matrix_mode)
     net, _ = make_models(args.model)
 
     frames_per_gpu = int(round(args.hours * FRAMES_PER_HOUR))
@@ -199,7 +202,8 @@ def main():
                    'pipe': 'fp32 vector ALU (same FMA lanes as fp32 MFMA)',
                    'hbm_GBs': fe_gbs, 'hbm_frac': fe_gbs / PEAK_HBM_GBS, 'bytes_per_frame': FRONTEND_BYTES_PER_FRAME}
         out = {
-            'metric': 'audio-hours processed/sec (MFCC+GRU-30k VAD)', 'value': value, 'unit': 'audio-hours/s',
+            'metric': 'audio-hours processed/sec (MFCC+GRU-30k VAD)' if args.model == 'gru_large'
+                      else 'audio-hours processed/sec (MFCC+%s VAD)' % args.model, 'value': value, 'unit': 'audio-hours/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -210,6 +214,26 @@ def main():
             'roofline': model_roof if nn_ms >= fe_ms else fe_roof,          # the longer of the two kernels
             'kernels': {'model': model_roof, 'frontend': fe_roof},
         }
+        if world == 1 and args.matrix_mode == 'f32' and args.model in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
+            # Not part of `value`: the same step with the recurrent and head products on the bf16 matrix pipe
+            # (float32 operands split exactly into three bf16; vad_set_matrix_mode), and how far its posteriors
+            # are from the float32-MFMA ones over every window of the workload.
+            p_f32 = ws.p.clone()
+            alt = {}
+            for mm in ('bf16x9', 'bf16x6'):
+                pkg.set_matrix_mode(mm)
+                step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t1) / 3
+                alt[mm] = {'value': hours_per_step / dt, 'unit': 'audio-hours/s', 'ms_per_step': dt * 1e3,
+                           'max_abs_posterior_diff_vs_f32': float((ws.p - p_f32).abs().max())}
+            pkg.set_matrix_mode('f32')
+            out['alt_matrix_modes'] = alt
+            del p_f32
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(args.model)
         print(json.dumps(out), flush=True)

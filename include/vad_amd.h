@@ -160,6 +160,22 @@ int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t wind
                              void* stream);
 
 /*
+ * How the stride-1 (window_stride == 24) GRU / LSTM kernels with hidden <= 32 form the float32 products
+ * of the recurrence and of the 26-row head.  Process-wide; no counterpart in the reference.
+ *   VAD_MATRIX_F32     v_mfma_f32_32x32x2_f32: a float32 FMA chain (default).
+ *   VAD_MATRIX_BF16X9  every float32 operand is split exactly into three bfloat16 and all nine partial
+ *                      products are accumulated in float32 on the bf16 matrix pipe: the products are
+ *                      exact, only the float32 accumulation rounds (in a different order than above).
+ *   VAD_MATRIX_BF16X6  as above without the three smallest partial products (<= 2^-23 of a product).
+ * Other strides, sampled windows, wider GRUs and DenseNet always compute as VAD_MATRIX_F32.
+ */
+#define VAD_MATRIX_F32 0
+#define VAD_MATRIX_BF16X6 1
+#define VAD_MATRIX_BF16X9 2
+int vad_set_matrix_mode(int mode);
+int vad_get_matrix_mode(void);
+
+/*
  * Sampled windows: window w starts at feature row window_rows_dev[w] of a packed
  * (n_rows, 24) matrix.  This is the access pattern of the reference's batch
  * provider, DataGenerator.get_batch (core/generator.py:111-165), which draws

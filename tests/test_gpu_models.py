@@ -244,3 +244,35 @@ def test_generator_feeds_models_without_batches(vad):
     np.testing.assert_array_equal(scores['batch'][0], scores['rows'][0])
     np.testing.assert_array_equal(scores['batch'][1], scores['rows'][1])
     assert len(scores['rows'][1]) > 0
+
+
+@pytest.mark.parametrize('mode', ['bf16x9', 'bf16x6'])
+@pytest.mark.parametrize('kind', ['gru_large', 'gru_small', 'lstm_large', 'lstm_small'])
+def test_split_bf16_matrix_modes(vad, kind, mode):
+    """The stride-1 kernels with the products on the bf16 matrix pipe (float32 operands split exactly into
+    three bf16) hold the same 1e-5 bar against the float32 oracle, and stay close to the float32-MFMA kernel."""
+    ref = models_ref.make_model(kind)
+    net = _gpu_model(vad, kind, ref)
+    rng = np.random.default_rng(41)
+    feat_np = rng.normal(0, 10, size=(1500, 24)).astype(np.float32)
+    feat_np[200:260] = 0.0
+    feat_np[700:705] *= 30.0                                   # outliers: saturated gates
+    feat = torch.tensor(feat_np).cuda()
+    p32, d32 = net.score(feat, window_stride=24)
+    prev = vad.set_matrix_mode(mode)
+    try:
+        assert prev == 'f32'
+        p, d = net.score(feat, window_stride=24)
+        p_again, _ = net.score(feat, window_stride=24)
+    finally:
+        vad.set_matrix_mode('f32')
+    assert torch.equal(p, p_again)                              # deterministic
+    windows = torch.stack([feat[i:i + 30] for i in range(1471)])
+    with torch.no_grad():
+        y = ref(windows.cpu()).numpy()
+    err = np.abs(p.cpu().numpy() - y).max()
+    assert err <= ATOL, err
+    assert np.abs(p.cpu().numpy() - p32.cpu().numpy()).max() <= ATOL
+    _decisions_agree(d.cpu().numpy(), y)
+    with pytest.raises(ValueError):
+        vad.set_matrix_mode('fp8')

@@ -34,3 +34,23 @@ for kind in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small', 'densenet', '
     print('%-15s posterior err: same features max %.2e | own features max %.2e ; decisions differing %d / %d (same), %d (own)'
           % (kind, np.abs(p_same.cpu().numpy() - y).max(), np.abs(p_e2e.cpu().numpy() - y).max(),
              int((d_same.cpu().numpy() != ref_dec).sum()), len(y), int((d_e2e.cpu().numpy() != ref_dec).sum())))
+
+# float32 products on the bf16 matrix pipe (vad_set_matrix_mode) against a float64 evaluation of the same models:
+# how far each kernel -- and float32 PyTorch on the CPU -- is from the exact answer
+print('\nerror against float64 evaluation of the same weights (20000 windows):')
+x64 = torch.from_numpy(xw[:20000].astype(np.float64))
+fdev = torch.from_numpy(ref[:20029].astype(np.float32)).cuda()
+for kind in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
+    r = models_ref.make_model(kind)
+    net = pkg.Net(large=kind.endswith('large'), lstm=kind.startswith('lstm'))
+    net.load_state_dict(r.state_dict())
+    y32 = pipeline_ref.score_windows(r, xw[:20000])
+    with torch.no_grad():
+        y64 = r.double()(x64).numpy()
+    row = ['torch-cpu-f32 %.2e' % np.abs(y32 - y64).max()]
+    for mode in ('f32', 'bf16x9', 'bf16x6'):
+        pkg.set_matrix_mode(mode)
+        p, _ = net.score(fdev, window_stride=24)
+        row.append('%s max %.2e mean %.2e' % (mode, np.abs(p.cpu().numpy() - y64).max(), np.abs(p.cpu().numpy() - y64).mean()))
+    pkg.set_matrix_mode('f32')
+    print('%-12s ' % kind + ' | '.join(row))

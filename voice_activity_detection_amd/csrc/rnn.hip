@@ -38,6 +38,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "rnn_device.h"
@@ -45,6 +46,9 @@
 namespace vad {
 
 using namespace rnn;
+
+// How the stride-1 GRU / LSTM kernels form their float32 matrix products (vad_set_matrix_mode).
+std::atomic<int> g_matrix_mode{VAD_MATRIX_F32};
 
 namespace {
 
@@ -102,14 +106,13 @@ __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x
         }
         // recurrent product, K = 32: k-step i takes unit u(i, half) = the lane's own h[i]; h_0 = 0
         if (t > 0) recurrent_mfma<LSTM, KS>(acc, h, a_hh, lane);
-        float a1v[KS];                                   // issued here, consumed after the gate math
-#pragma unroll
-        for (int i = 0; i < KS; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
+        HeadWeights<LARGE, KS> hw;                       // issued here, consumed after the gate math
+        head_load<LARGE, KS>(hw, a1, t, lane);
         gate_update<LSTM>(acc, h, c);
         // head: flatten index is t * H + unit
-#pragma unroll
-        for (int i = 0; i < KS; ++i) lacc = MFMA(a1v[i], h[i], lacc);
+        head_step<LARGE, KS>(lacc, hw, h);
     }
+    head_finish<LARGE>(lacc);
     head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
 }
 
@@ -177,9 +180,8 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
     const float* girow = gi + (wave * kWindowsPerWave + col) * C::rs + 4 * half;
 
     for (int t = 0; t < kT; ++t) {
-        float a1v[KS];
-#pragma unroll
-        for (int i = 0; i < KS; ++i) a1v[i] = a1[(t * kHk + i) * 64 + lane];
+        HeadWeights<LARGE, KS> hw;
+        head_load<LARGE, KS>(hw, a1, t, lane);
         f32x16 acc[4];
         const float* src = girow + t * C::rs;
 #pragma unroll
@@ -192,9 +194,111 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
         if (!LSTM) acc[3] = load16(cb + (3 * 2 + half) * 16);    // b_hn
         if (t > 0) recurrent_mfma<LSTM, KS>(acc, h, a_hh, lane);
         gate_update<LSTM>(acc, h, c);
-#pragma unroll
-        for (int i = 0; i < KS; ++i) lacc = MFMA(a1v[i], h[i], lacc);
+        head_step<LARGE, KS>(lacc, hw, h);
     }
+    head_finish<LARGE>(lacc);
+    head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same stride-1 kernel with the recurrent product and the 26-row head on the bf16 matrix pipe
+// (float32 operands split exactly into three bf16, TERMS partial products per product; rnn_device.h).
+// The input projection (1/30 of the matrix work) stays on the float32 MFMA.
+
+template <bool LSTM>
+struct SplitCfg : StreamCfg<LSTM> {
+    static constexpr int lds_floats = StreamCfg<LSTM>::gi_floats + StreamCfg<LSTM>::G * kSplitTile + 4 * 2 * 16;
+};
+
+template <bool LSTM, bool LARGE, int TERMS>
+__global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_split_kernel(
+    const float* __restrict__ feat, long n_windows, const float* __restrict__ blob, float* __restrict__ p_out,
+    uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    using C = SplitCfg<LSTM>;
+    constexpr int G = C::G;
+    extern __shared__ __align__(16) float lds[];
+    const NetLayout L = net_layout(LSTM, LARGE);
+    float* gi = lds;                                             // [tiles * 32 rows][rs]
+    float* s_hh = lds + C::gi_floats;                            // [G] split tiles
+    float* cb = s_hh + G * kSplitTile;
+    for (int i = threadIdx.x; i < G * kSplitTile; i += C::waves * 64) s_hh[i] = blob[L.s_hh + i];
+    for (int i = threadIdx.x; i < 4 * 2 * 16; i += C::waves * 64) cb[i] = blob[L.cb + i];
+
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    const long w0 = (long)blockIdx.x * C::windows;
+    const long last_row = n_windows + kT - 2;
+
+    // ---- phase 1: gi[row][gate * 32 + unit] = bias + W_ih x_row (float32 MFMA, as rnn_stream_kernel) ----
+    for (int task = wave; task < C::tiles * G; task += C::waves) {
+        const int tile = task / G, g = task - tile * G;
+        long row = w0 + tile * 32 + col;
+        if (row > last_row) row = last_row;
+        const float* xr = feat + row * kF + 12 * half;
+        const float4 xa = *reinterpret_cast<const float4*>(xr), xb = *reinterpret_cast<const float4*>(xr + 4),
+                     xc = *reinterpret_cast<const float4*>(xr + 8);
+        const float xv[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+        f32x16 acc = load16(blob + L.cb + (g * 2 + half) * 16);
+#pragma unroll
+        for (int s = 0; s < kKs; ++s) acc = MFMA(blob[L.a_ih + (g * kKs + s) * 64 + lane], xv[s], acc);
+        float* dst = gi + (tile * 32 + col) * C::rs + g * 32 + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    __syncthreads();
+
+    // ---- phase 2: 30 steps for the wave's 32 windows.  A wave alternates between a matrix phase (18 or 27
+    // bf16 MFMAs per tile) and a vector phase (gate math, bf16 split); the two waves that share a SIMD
+    // (w and w + 4) overlap only while they are in different phases, and left alone they start in lockstep,
+    // so the second one is delayed once by about half a step. ----
+    const long w = w0 + wave * kWindowsPerWave + col;
+    if (w0 + wave * kWindowsPerWave >= n_windows) return;       // wave-uniform, after the only barrier
+    const float* a1 = blob + L.head;
+    const u32x4* s_gate = reinterpret_cast<const u32x4*>(s_hh);
+    const u32x4* s_head = reinterpret_cast<const u32x4*>(blob + L.s_head);
+    f32x16 h, c, lacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { h[i] = 0.0f; c[i] = 0.0f; lacc[i] = 0.0f; }
+    const float* girow = gi + (wave * kWindowsPerWave + col) * C::rs + 4 * half;
+    SplitB b;
+#ifndef VAD_SPLIT_STAGGER
+#define VAD_SPLIT_STAGGER 14
+#endif
+    if ((wave >> 2) != 0 && VAD_SPLIT_STAGGER > 0) __builtin_amdgcn_s_sleep(VAD_SPLIT_STAGGER);   // x 64 cycles
+
+    for (int t = 0; t < kT; ++t) {
+        HeadWeights<false, kHk> hw;                              // 2-row head: vector ALU, float32 weights
+        if (!LARGE) head_load<false, kHk>(hw, a1, t, lane);
+        f32x16 acc[4];
+        const float* src = girow + t * C::rs;
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(src + g * 32 + 8 * q);
+                acc[g][4 * q] = v.x; acc[g][4 * q + 1] = v.y; acc[g][4 * q + 2] = v.z; acc[g][4 * q + 3] = v.w;
+            }
+        if (!LSTM) acc[3] = load16(cb + (3 * 2 + half) * 16);    // b_hn
+        if (t > 0) {                                             // b holds the split of h_{t-1}
+            if (LARGE) lacc = split_tile_mfma<TERMS>(lacc, s_head + (t - 1) * (kSplitTile / 4), b, lane);
+            if (LSTM) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = split_tile_mfma<TERMS>(acc[g], s_gate + g * (kSplitTile / 4), b, lane);
+            } else {
+                acc[0] = split_tile_mfma<TERMS>(acc[0], s_gate + 0 * (kSplitTile / 4), b, lane);
+                acc[1] = split_tile_mfma<TERMS>(acc[1], s_gate + 1 * (kSplitTile / 4), b, lane);
+                acc[3] = split_tile_mfma<TERMS>(acc[3], s_gate + 2 * (kSplitTile / 4), b, lane);
+            }
+        }
+        gate_update<LSTM>(acc, h, c);
+        split_state(b, h);                                       // for this step's head and the next step's gates
+        if (!LARGE) head_step<false, kHk>(lacc, hw, h);
+    }
+    if (LARGE) lacc = split_tile_mfma<TERMS>(lacc, s_head + (kT - 1) * (kSplitTile / 4), b, lane);
+    head_finish<LARGE>(lacc);
     head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
 }
 
@@ -309,6 +413,14 @@ int ensure_rnn_attrs() {
     if ((rc = allow_lds(&rnn_stream_kernel<false, true, 16>, StreamCfg<false>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_kernel<true, false, 16>, StreamCfg<true>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_kernel<true, true, 16>, StreamCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<false, false, 6>, SplitCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 6>, SplitCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 6>, SplitCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<true, true, 6>, SplitCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<false, false, 9>, SplitCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 9>, SplitCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 9>, SplitCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<true, true, 9>, SplitCfg<true>::lds_floats))) return rc;
     if ((rc = allow_lds(&gru_wide_kernel<false, 2>, net_layout(false, false, 2).head))) return rc;
     if ((rc = allow_lds(&gru_wide_kernel<true, 2>, net_layout(false, true, 2).head))) return rc;
     if ((rc = allow_lds(&gru_wide_kernel<false, 3>, net_layout(false, false, 3).head))) return rc;
@@ -341,6 +453,23 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
 template <bool LSTM, bool LARGE, int KS>
 int launch_ks(const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec, int mode,
            float threshold, hipStream_t st) {
+    const int matrix_mode = g_matrix_mode.load(std::memory_order_relaxed);
+    if (!wm.rows && wm.stride == kF && matrix_mode != VAD_MATRIX_F32) {
+        using C = SplitCfg<LSTM>;
+        int rc = ensure_rnn_attrs();
+        if (rc != VAD_OK) return rc;
+        const size_t lds_bytes = (size_t)C::lds_floats * sizeof(float);
+        const long blocks = (n_windows + C::windows - 1) / C::windows;
+        VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
+        if (matrix_mode == VAD_MATRIX_BF16X9)
+            hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, 9>), dim3((unsigned)blocks), dim3(C::waves * 64),
+                               lds_bytes, st, x, n_windows, blob, p, dec, mode, threshold);
+        else
+            hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, 6>), dim3((unsigned)blocks), dim3(C::waves * 64),
+                               lds_bytes, st, x, n_windows, blob, p, dec, mode, threshold);
+        VAD_HIP_CHECK(hipGetLastError());
+        return VAD_OK;
+    }
     if (!wm.rows && wm.stride == kF) {
         using C = StreamCfg<LSTM>;
         int rc = ensure_rnn_attrs();
@@ -403,6 +532,15 @@ int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, cons
 }
 
 }  // namespace vad
+
+extern "C" int vad_set_matrix_mode(int mode) {
+    VAD_REQUIRE(mode == VAD_MATRIX_F32 || mode == VAD_MATRIX_BF16X6 || mode == VAD_MATRIX_BF16X9,
+                "unknown matrix mode %d", mode);
+    vad::g_matrix_mode.store(mode, std::memory_order_relaxed);
+    return VAD_OK;
+}
+
+extern "C" int vad_get_matrix_mode(void) { return vad::g_matrix_mode.load(std::memory_order_relaxed); }
 
 extern "C" size_t vad_net_blob_floats(int lstm, int large, int hidden) {
     if (hidden < 1 || hidden > (lstm ? vad::kHp : 3 * vad::kHp)) return 0;
@@ -484,6 +622,35 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
     } else {
         tail[0] = lin_b[0];
         tail[1] = lin_b[1];
+    }
+    if (UT == 1) {
+        // bf16 (hi, mid, lo) images of the float32 A operands above: element j of k-step s (of 16) is the
+        // float32 k-step 8 s + j of the same lane
+        auto split_tile = [&](const float* a16, float* dst) {      // a16: [16][64] floats -> [2][3][64][8 bf16]
+            uint16_t* out = reinterpret_cast<uint16_t*>(dst);
+            for (int s = 0; s < 2; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = a16[(8 * s + j) * 64 + lane];
+                        uint32_t bits;
+                        memcpy(&bits, &x, 4);
+                        const uint32_t hb = bits & 0xFFFF0000u;
+                        float hi;
+                        memcpy(&hi, &hb, 4);
+                        const float r1 = x - hi;
+                        memcpy(&bits, &r1, 4);
+                        const uint32_t mb = bits & 0xFFFF0000u;
+                        float mid;
+                        memcpy(&mid, &mb, 4);
+                        const float r2 = r1 - mid;
+                        memcpy(&bits, &r2, 4);
+                        out[(((s * 3 + 0) * 64 + lane) * 8) + j] = (uint16_t)(hb >> 16);
+                        out[(((s * 3 + 1) * 64 + lane) * 8) + j] = (uint16_t)(mb >> 16);
+                        out[(((s * 3 + 2) * 64 + lane) * 8) + j] = (uint16_t)(bits >> 16);
+                    }
+        };
+        for (int g = 0; g < G; ++g) split_tile(blob + L.a_hh + g * kHk * 64, blob + L.s_hh + g * kSplitTile);
+        for (int t = 0; t < kT; ++t) split_tile(blob + L.head + t * kHk * 64, blob + L.s_head + t * kSplitTile);
     }
     return VAD_OK;
 }

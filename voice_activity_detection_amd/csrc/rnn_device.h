@@ -29,8 +29,12 @@ struct NetLayout {
     int cb;           // [4][ut][2][16]             accumulator initial values (biases), per lane half
     int head;         // a1 [30][ut*16][64]         A operands of lin1 (large) or lin (small, rows 0-1)
     int tail;         // large: b1e [2][16], w2e [2][2][16], b2 [2] (+2 pad); small: bl [2] (+2 pad)
+    int s_hh;         // ut == 1 only: [gates][2][3][64] x 8 bf16   a_hh split into bf16 (hi, mid, lo) A operands
+    int s_head;       // ut == 1 only: [30][2][3][64] x 8 bf16      the head's A operands, split the same way
     int total;
 };
+
+constexpr int kSplitTile = 2 * 3 * 64 * 4;   // dwords of one split 32x32 A tile: 2 k-steps of 16, 3 terms, 16 B per lane
 
 __host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 1) {
     NetLayout L;
@@ -41,7 +45,9 @@ __host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 
     L.cb = L.a_hh + L.gates * ut * ut * kHk * 64;
     L.head = L.cb + 4 * ut * 2 * 16;
     L.tail = L.head + kT * ut * kHk * 64;
-    L.total = L.tail + (large ? (2 * 16 + 2 * 2 * 16 + 4) : 4);
+    L.s_hh = L.tail + (large ? (2 * 16 + 2 * 2 * 16 + 4) : 4);
+    L.s_head = L.s_hh + (ut == 1 ? L.gates * kSplitTile : 0);
+    L.total = L.s_head + (ut == 1 ? kT * kSplitTile : 0);
     return L;
 }
 
@@ -76,6 +82,64 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ---- fp32 products on the bf16 matrix pipe ---------------------------------------------------------
+// A float32 is the exact sum of three bfloat16 (8 + 8 + 8 significant bits, by truncation: hi = the upper
+// 16 bits, mid = the upper 16 bits of x - hi, lo = x - hi - mid).  x * y is then the exact sum of the nine
+// bf16 x bf16 partial products, each of which v_mfma_f32_32x32x16_bf16 forms exactly and adds in float32.
+// With all 9 terms the only rounding left is the float32 accumulation, as in a float32 FMA chain; with 6
+// terms the three smallest (mid*lo, lo*mid, lo*lo, <= 2^-23 of the product) are dropped.  A bf16 MFMA
+// costs 32 cycles for K = 16 against 8 x 64 cycles for the same K on the float32 MFMA, and unlike the
+// float32 MFMA it runs beside vector instructions.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA_BF16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// B operands (hi, mid, lo) of the lane's registers 8 s .. 8 s + 7, s = 0, 1: element j of k-step s is register 8 s + j
+struct SplitB {
+    u32x4 hi[2], mid[2], lo[2];
+};
+
+__device__ __forceinline__ void split_state(SplitB& b, const f32x16& h) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            const float x0 = h[8 * s + 2 * jp], x1 = h[8 * s + 2 * jp + 1];
+            const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
+            const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+            const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
+            const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+            // upper halves of (second, first) -> one dword, first in the low half
+            b.hi[s][jp] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+            b.mid[s][jp] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+            b.lo[s][jp] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+        }
+}
+
+// acc += A . B for one split 32x32 tile; `a` points at the tile's [2][3][64] 16-byte entries (LDS or global)
+template <int TERMS>
+__device__ __forceinline__ f32x16 split_tile_mfma(f32x16 acc, const u32x4* a, const SplitB& b, int lane) {
+    static_assert(TERMS == 6 || TERMS == 9, "6 or 9 partial products");
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const u32x4 ah = a[(s * 3 + 0) * 64 + lane], am = a[(s * 3 + 1) * 64 + lane], al = a[(s * 3 + 2) * 64 + lane];
+        if (TERMS == 9) {                                   // smallest terms first
+            acc = MFMA_BF16(al, b.lo[s], acc);
+            acc = MFMA_BF16(am, b.lo[s], acc);
+            acc = MFMA_BF16(al, b.mid[s], acc);
+        }
+        acc = MFMA_BF16(ah, b.lo[s], acc);
+        acc = MFMA_BF16(al, b.hi[s], acc);
+        acc = MFMA_BF16(am, b.mid[s], acc);
+        acc = MFMA_BF16(ah, b.mid[s], acc);
+        acc = MFMA_BF16(am, b.hi[s], acc);
+        acc = MFMA_BF16(ah, b.hi[s], acc);
+    }
+    return acc;
+}
 
 __device__ __forceinline__ f32x16 load16(const float* p) {      // 16 consecutive floats, 16-byte aligned
     const float4* s = reinterpret_cast<const float4*>(p);
@@ -124,6 +188,53 @@ __device__ __forceinline__ void gate_update(const f32x16 (&acc)[4], f32x16& h, f
             const float n = tanh_pre(fmaf(r, acc[3][i], acc[2][i]));
             h[i] = fmaf(z, h[i] - n, n);
         }
+    }
+}
+
+// The step-t slice of the flattened head (lin1: 26 rows, or lin: 2 rows): out[o] += W[o][t*H + u] h_t[u].
+// Its weights sit in the blob as MFMA A operands, a1[(t*16 + i)*64 + lane] = W[lane & 31][t*H + u(i, lane >> 5)].
+// The 26-row head is one more matrix-core tile.  The 2-row head would fill 2 of a tile's 32 rows, so it runs
+// on the vector ALU instead: each lane multiplies its own 16 units into two running sums (the weights of
+// rows 0 and 1 are the adjacent floats at lane positions 32*half and 32*half + 1, the same for the whole
+// half-wave) and the two half-waves are added once, after the last step (head_finish).
+template <bool LARGE, int KS>
+struct HeadWeights {
+    float a[LARGE ? KS : 1];
+    float2 w[LARGE ? 1 : KS];
+};
+
+template <bool LARGE, int KS>
+__device__ __forceinline__ void head_load(HeadWeights<LARGE, KS>& hw, const float* __restrict__ a1, int t, int lane) {
+    if (LARGE) {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) hw.a[i] = a1[(t * kHk + i) * 64 + lane];
+    } else {
+        const float2* p = reinterpret_cast<const float2*>(a1 + (long)t * kHk * 64 + 32 * (lane >> 5));
+#pragma unroll
+        for (int i = 0; i < KS; ++i) hw.w[i] = p[i * 32];
+    }
+}
+
+template <bool LARGE, int KS>
+__device__ __forceinline__ void head_step(f32x16& lacc, const HeadWeights<LARGE, KS>& hw, const f32x16& h) {
+    if (LARGE) {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) lacc = MFMA(hw.a[i], h[i], lacc);
+    } else {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            lacc[0] = fmaf(hw.w[i].x, h[i], lacc[0]);
+            lacc[1] = fmaf(hw.w[i].y, h[i], lacc[1]);
+        }
+    }
+}
+
+// after the last step: lacc in the accumulator layout head_epilogue reads
+template <bool LARGE>
+__device__ __forceinline__ void head_finish(f32x16& lacc) {
+    if (!LARGE) {
+        lacc[0] += __shfl_xor(lacc[0], 32, 64);
+        lacc[1] += __shfl_xor(lacc[1], 32, 64);
     }
 }
 

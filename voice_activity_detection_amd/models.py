@@ -19,6 +19,20 @@ from .common import BATCH_SIZE, FEATURES, FRAMES
 
 DECIDE_ARGMAX = 0
 DECIDE_THRESHOLD = 1
+MATRIX_MODES = {'f32': 0, 'bf16x6': 1, 'bf16x9': 2}
+
+
+def set_matrix_mode(mode):
+    """Process-wide: how the stride-1 GRU / LSTM kernels form their float32 matrix products.
+    'f32' (default) is the float32 MFMA; 'bf16x9' splits every float32 operand exactly into three bfloat16
+    and accumulates all nine partial products in float32 on the bf16 matrix pipe; 'bf16x6' drops the
+    three smallest partial products.  Returns the previous mode's name."""
+    L = _lib.lib()
+    if mode not in MATRIX_MODES:
+        raise ValueError('matrix mode must be one of %s' % sorted(MATRIX_MODES))
+    prev = L.vad_get_matrix_mode()
+    _lib.check(L.vad_set_matrix_mode(MATRIX_MODES[mode]))
+    return {v: k for k, v in MATRIX_MODES.items()}[prev]
 
 
 def _cuda_device():
