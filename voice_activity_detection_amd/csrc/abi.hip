@@ -68,7 +68,9 @@ extern "C" const char* vad_last_error(void) { return vad::g_err; }
 extern "C" int vad_init(void) {
     int rc = vad::ensure_mfcc_tables();
     if (rc != VAD_OK) return rc;
-    return vad::ensure_rnn_attrs();
+    rc = vad::ensure_rnn_attrs();
+    if (rc != VAD_OK) return rc;
+    return vad::ensure_densenet_attrs();
 }
 
 extern "C" int vad_synth_audio_i16(int16_t* out_dev, int64_t first_sample, int64_t n_samples, uint32_t seed,

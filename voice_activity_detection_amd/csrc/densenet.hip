@@ -19,6 +19,7 @@
 
 #include <math.h>
 #include <string.h>
+#include <mutex>
 
 #include "vad_internal.h"
 
@@ -99,11 +100,26 @@ __device__ __forceinline__ f32x16 load_shift(const float* p, int half) {
     return r;
 }
 
-// One dense block: NL growth layers over L positions, appended channel by channel to act[].
+// Where a wave's activations live.  Channels below `split` (the stem / transition outputs) are read at
+// a[c * a_c + l * a_l], the growth channels appended by a dense block at b[(c - split) * b_c + l * b_l];
+// both bases already include the lane's window.  The stride-1 kernel points `a` at a block-shared image of
+// the stem output, the generic kernel at its private copy.
+struct ActView {
+    const float* a;
+    int a_c, a_l;
+    float* b;
+    int b_c, b_l;
+    int split;
+    __device__ __forceinline__ float ld(int c, int l) const {
+        return c < split ? a[c * a_c + l * a_l] : b[(c - split) * b_c + l * b_l];
+    }
+};
+
+// One dense block: NL growth layers over L positions, appended channel by channel.
 template <int NL, int G, int L>
-__device__ __forceinline__ void dense_block(float* act, const float* __restrict__ block_w, int c_first, int col,
-                                            int half) {
-    for (int layer = 0; layer < NL; ++layer) {
+__device__ __forceinline__ void dense_block(const ActView& v, const float* __restrict__ block_w, int c_first, int half) {
+#pragma unroll
+    for (int layer = 0; layer < NL; ++layer) {                    // unrolled: the channel count below is a constant
         const int cin = c_first + G * layer;
         const float* wl = block_w + dense_layer_offset(c_first, G, layer);
         float acc[G][L];
@@ -111,10 +127,10 @@ __device__ __forceinline__ void dense_block(float* act, const float* __restrict_
         for (int o = 0; o < G; ++o)
 #pragma unroll
             for (int l = 0; l < L; ++l) acc[o][l] = 0.0f;
-        for (int c = half; c < cin; c += 2) {
+        auto channel = [&](int c, const float* src, int sl) {
             float a[L];
 #pragma unroll
-            for (int l = 0; l < L; ++l) a[l] = act[(c * L + l) * 32 + col];
+            for (int l = 0; l < L; ++l) a[l] = src[l * sl];
             const float4* wp = reinterpret_cast<const float4*>(wl + c * 12);
             const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
             const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
@@ -127,68 +143,74 @@ __device__ __forceinline__ void dense_block(float* act, const float* __restrict_
                     if (l < L - 1) s = fmaf(w[o * 3 + 2], a[l + 1], s);
                     acc[o][l] = s;
                 }
-        }
+        };
+        // The lane halves take the even / the odd channels (c_first is even, so both halves leave the first
+        // range together).  A wave is nearly alone on its SIMD (LDS-bound occupancy), so the weight loads
+        // of several channels have to be in flight at once: the unrolled iterations are independent until
+        // the accumulation.
+#pragma unroll 4
+        for (int c = half; c < c_first; c += 2) channel(c, v.a + c * v.a_c, v.a_l);
+#pragma unroll 4
+        for (int c = c_first + half; c < cin; c += 2) channel(c, v.b + (c - c_first) * v.b_c, v.b_l);
         const float4 sh4 = *reinterpret_cast<const float4*>(wl + cin * 12);
         const float sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
         for (int o = 0; o < G; ++o)
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                const float v = lrelu(acc[o][l] + __shfl_xor(acc[o][l], 32, 64) + sh[o]);
-                if (half == 0) act[((cin + o) * L + l) * 32 + col] = v;
+                const float y = lrelu(acc[o][l] + __shfl_xor(acc[o][l], 32, 64) + sh[o]);
+                if (half == 0) v.b[(cin + o - c_first) * v.b_c + l * v.b_l] = y;
             }
         wave_lds_fence();
     }
 }
 
-template <bool LARGE>
-__global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ x, long n_windows, WindowMap wm,
-                                                      const float* __restrict__ blob, float* __restrict__ p_out,
-                                                      uint8_t* __restrict__ dec_out, int mode, float threshold) {
+// Stem for one tile of 32 columns: Conv1d(24 -> c0, k = 6, dilation 4) + BN at two adjacent positions
+// (`xe` and the row after it), max-pooled and passed through LeakyReLU.  out(mt, i, value) receives
+// accumulator register i of channel tile mt.
+template <bool LARGE, typename Out>
+__device__ __forceinline__ void stem_pair(const float* xe_row, const float* __restrict__ blob, const DnLayout& LY, int lane,
+                                          int half, Out out) {
     using D = Dims<LARGE>;
-    __shared__ __align__(16) float act[D::c1 * kL1 * 32];
-    const DnLayout LY = dn_layout<LARGE>();
-    const int lane = threadIdx.x;
-    const int half = lane >> 5;
-    const int col = lane & 31;
-    const long w = (long)blockIdx.x * 32 + col;
-    const long wc = w < n_windows ? w : n_windows - 1;
-    const float* xw = window_ptr(x, wm, wc) + 12 * half;
-
-    // ---- stem: Conv1d(24 -> c0, k = 6, dilation 4) + BN + MaxPool(2) + LeakyReLU, 30 -> 10 -> 5 ----
-    for (int lp = 0; lp < kL1; ++lp) {
-        f32x16 acc_e[D::mt0], acc_o[D::mt0];
+    f32x16 acc_e[D::mt0], acc_o[D::mt0];
 #pragma unroll
-        for (int mt = 0; mt < D::mt0; ++mt) acc_e[mt] = acc_o[mt] = load_shift(blob + LY.s_in + mt * 32, half);
-        for (int j = 0; j < kTaps; ++j) {
-            const float* re = xw + (2 * lp + 4 * j) * kF;        // even position 2 lp reads row 2 lp + 4 j
-            const float4 e0 = *reinterpret_cast<const float4*>(re), e1 = *reinterpret_cast<const float4*>(re + 4),
-                         e2 = *reinterpret_cast<const float4*>(re + 8);
-            const float4 o0 = *reinterpret_cast<const float4*>(re + kF), o1 = *reinterpret_cast<const float4*>(re + kF + 4),
-                         o2 = *reinterpret_cast<const float4*>(re + kF + 8);
-            const float xe[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
-            const float xo[12] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w};
+    for (int mt = 0; mt < D::mt0; ++mt) acc_e[mt] = acc_o[mt] = load_shift(blob + LY.s_in + mt * 32, half);
 #pragma unroll
-            for (int s = 0; s < 12; ++s)
+    for (int j = 0; j < kTaps; ++j) {
+        const float* re = xe_row + 4 * j * kF;                   // tap j reads the row 4 j later (dilation 4)
+        const float4 e0 = *reinterpret_cast<const float4*>(re), e1 = *reinterpret_cast<const float4*>(re + 4),
+                     e2 = *reinterpret_cast<const float4*>(re + 8);
+        const float4 o0 = *reinterpret_cast<const float4*>(re + kF), o1 = *reinterpret_cast<const float4*>(re + kF + 4),
+                     o2 = *reinterpret_cast<const float4*>(re + kF + 8);
+        const float xe[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+        const float xo[12] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w};
 #pragma unroll
-                for (int mt = 0; mt < D::mt0; ++mt) {
-                    const float a = blob[LY.a_in + ((mt * kTaps + j) * 12 + s) * 64 + lane];
-                    acc_e[mt] = MFMA(a, xe[s], acc_e[mt]);
-                    acc_o[mt] = MFMA(a, xo[s], acc_o[mt]);
-                }
-        }
+        for (int s = 0; s < 12; ++s)
 #pragma unroll
-        for (int mt = 0; mt < D::mt0; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = 32 * mt + mfma32_row(i, half);
-                if (c < D::c0) act[(c * kL1 + lp) * 32 + col] = lrelu(fmaxf(acc_e[mt][i], acc_o[mt][i]));
+            for (int mt = 0; mt < D::mt0; ++mt) {
+                const float a = blob[LY.a_in + ((mt * kTaps + j) * 12 + s) * 64 + lane];
+                acc_e[mt] = MFMA(a, xe[s], acc_e[mt]);
+                acc_o[mt] = MFMA(a, xo[s], acc_o[mt]);
             }
     }
-    wave_lds_fence();
+#pragma unroll
+    for (int mt = 0; mt < D::mt0; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out(mt, i, lrelu(fmaxf(acc_e[mt][i], acc_o[mt][i])));
+}
+
+// Everything after the stem for a wave's 32 windows: dense block 1 over `v1`, transition into the plain
+// private array act2[c][2][32] (which may alias v1's growth region), dense block 2, cnn_out, Linear, softmax.
+template <bool LARGE>
+__device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, const float* __restrict__ blob,
+                                              const DnLayout& LY, int lane, long w, long n_windows,
+                                              float* __restrict__ p_out, uint8_t* __restrict__ dec_out, int mode,
+                                              float threshold) {
+    using D = Dims<LARGE>;
+    const int half = lane >> 5, col = lane & 31;
 
     // ---- dense block 1 (5 positions) ----
-    dense_block<D::nl, D::g, kL1>(act, blob + LY.dense[0], D::c0, col, half);
+    dense_block<D::nl, D::g, kL1>(v1, blob + LY.dense[0], D::c0, half);
 
     // ---- transition: 1x1 conv c1 -> c0 + BN + MaxPool(2) + LeakyReLU, 5 -> 2 (position 4 is dropped) ----
     f32x16 tr[D::mt0][kL2];
@@ -197,10 +219,11 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
         f32x16 acc_e[D::mt0], acc_o[D::mt0];
 #pragma unroll
         for (int mt = 0; mt < D::mt0; ++mt) acc_e[mt] = acc_o[mt] = load_shift(blob + LY.s_tr + mt * 32, half);
+#pragma unroll 8
         for (int s = 0; s < D::ks1; ++s) {
             const int c = 2 * s + half;
-            const float be = act[(c * kL1 + 2 * lp) * 32 + col];
-            const float bo = act[(c * kL1 + 2 * lp + 1) * 32 + col];
+            const float be = v1.ld(c, 2 * lp);
+            const float bo = v1.ld(c, 2 * lp + 1);
 #pragma unroll
             for (int mt = 0; mt < D::mt0; ++mt) {
                 const float a = blob[LY.a_tr + (mt * D::ks1 + s) * 64 + lane];
@@ -221,12 +244,13 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int c = 32 * mt + mfma32_row(i, half);
-                if (c < D::c0) act[(c * kL2 + lp) * 32 + col] = tr[mt][lp][i];
+                if (c < D::c0) act2[(c * kL2 + lp) * 32 + col] = tr[mt][lp][i];
             }
     wave_lds_fence();
 
     // ---- dense block 2 (2 positions) ----
-    dense_block<D::nl, D::g, kL2>(act, blob + LY.dense[1], D::c0, col, half);
+    const ActView v2{act2 + col, kL2 * 32, 32, act2 + D::c0 * kL2 * 32 + col, kL2 * 32, 32, D::c0};
+    dense_block<D::nl, D::g, kL2>(v2, blob + LY.dense[1], D::c0, half);
 
     // ---- cnn_out: 1x1 conv c1 -> c1 + BN + MaxPool(2) + LeakyReLU, 2 -> 1; then Linear(c1 -> 2) ----
     float l0 = 0.0f, l1 = 0.0f;
@@ -234,11 +258,12 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
     for (int mt = 0; mt < D::mt1; ++mt) {
         f32x16 acc_e, acc_o;
         acc_e = acc_o = load_shift(blob + LY.s_out + mt * 32, half);
+#pragma unroll 8
         for (int s = 0; s < D::ks1; ++s) {
             const int c = 2 * s + half;
             const float a = blob[LY.a_out + (mt * D::ks1 + s) * 64 + lane];
-            acc_e = MFMA(a, act[(c * kL2 + 0) * 32 + col], acc_e);
-            acc_o = MFMA(a, act[(c * kL2 + 1) * 32 + col], acc_o);
+            acc_e = MFMA(a, act2[(c * kL2 + 0) * 32 + col], acc_e);
+            acc_o = MFMA(a, act2[(c * kL2 + 1) * 32 + col], acc_o);
         }
         const float* wf0 = blob + LY.w_fin + ((mt * 2 + 0) * 2 + half) * 16;
         const float* wf1 = blob + LY.w_fin + ((mt * 2 + 1) * 2 + half) * 16;
@@ -259,6 +284,89 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
         *reinterpret_cast<float2*>(p_out + 2 * w) = make_float2(p0, p1);
         if (dec_out) dec_out[w] = (mode == VAD_DECIDE_THRESHOLD) ? (p1 >= threshold) : (p1 > p0);
     }
+}
+
+// Any window placement: one wave = one block = 32 windows, everything private.
+template <bool LARGE>
+__global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ x, long n_windows, WindowMap wm,
+                                                      const float* __restrict__ blob, float* __restrict__ p_out,
+                                                      uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    using D = Dims<LARGE>;
+    __shared__ __align__(16) float act[D::c1 * kL1 * 32];
+    const DnLayout LY = dn_layout<LARGE>();
+    const int lane = threadIdx.x;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const long w = (long)blockIdx.x * 32 + col;
+    const long wc = w < n_windows ? w : n_windows - 1;
+    const float* xw = window_ptr(x, wm, wc) + 12 * half;
+
+    // ---- stem: 30 rows -> 10 positions -> pooled to 5 ----
+    for (int lp = 0; lp < kL1; ++lp)
+        stem_pair<LARGE>(xw + 2 * lp * kF, blob, LY, lane, half, [&](int mt, int i, float y) {
+            const int c = 32 * mt + mfma32_row(i, half);
+            if (c < D::c0) act[(c * kL1 + lp) * 32 + col] = y;
+        });
+    wave_lds_fence();
+
+    const ActView v1{act + col, kL1 * 32, 32, act + D::c0 * kL1 * 32 + col, kL1 * 32, 32, D::c0};
+    densenet_tail<LARGE>(v1, act, blob, LY, lane, w, n_windows, p_out, dec_out, mode, threshold);
+}
+
+// Stride-1 windows over a packed (F, 24) matrix.  The stem output at pooled position lp of window w is
+// M[w + 2 lp], M[r] = LeakyReLU(max(S[r], S[r + 1])) with S[r] the stem convolution at absolute row r:
+// it belongs to the row, not to the window, and ten overlapping windows would each recompute it.  A block
+// of NW waves computes M once for its NW * 32 rows (one 32-row tile per wave) into a shared LDS image and
+// then scores its NW * 32 - 8 windows from it; only the growth channels are private to a wave.
+template <bool LARGE>
+struct DnStreamCfg {
+    using D = Dims<LARGE>;
+    static constexpr int waves = LARGE ? 6 : 8;
+    static constexpr int rows = waves * 32;                      // M rows per block
+    static constexpr int windows = rows - 8;                     // window w reads M[w .. w + 8]
+    static constexpr int grow = D::nl * D::g;                    // growth channels of a dense block
+    static constexpr int priv1 = grow * kL1 * 32, priv2 = D::c1 * kL2 * 32;
+    static constexpr int priv = priv1 > priv2 ? priv1 : priv2;   // per wave: block-1 growth channels, then all of block 2
+    static constexpr int lds_floats = D::c0 * rows + waves * priv;
+};
+
+template <bool LARGE>
+__global__ __launch_bounds__(DnStreamCfg<LARGE>::waves * 64) void densenet_stream_kernel(
+    const float* __restrict__ feat, long n_windows, const float* __restrict__ blob, float* __restrict__ p_out,
+    uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    using D = Dims<LARGE>;
+    using C = DnStreamCfg<LARGE>;
+    extern __shared__ __align__(16) float lds[];
+    float* M = lds;                                              // [c0][rows]
+    const DnLayout LY = dn_layout<LARGE>();
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    float* priv = lds + D::c0 * C::rows + wave * C::priv;
+    const long w0 = (long)blockIdx.x * C::windows;
+    const long last_row = n_windows + VAD_FRAMES - 2;            // the matrix has n_windows + 29 rows
+
+    // ---- phase 1: M for rows w0 + 32 wave + col.  S[r + 1] with tap 5 reads row r + 21; rows past the
+    // matrix (only reached by M entries that no valid window uses) are clamped to its last row. ----
+    {
+        const long r = w0 + wave * 32 + col;
+        const long rc = r + 21 <= last_row ? r : (last_row - 21 > 0 ? last_row - 21 : 0);
+        stem_pair<LARGE>(feat + rc * kF + 12 * half, blob, LY, lane, half, [&](int mt, int i, float y) {
+            const int c = 32 * mt + mfma32_row(i, half);
+            if (c < D::c0) M[c * C::rows + wave * 32 + col] = y;
+        });
+    }
+    __syncthreads();
+
+    // ---- phase 2: the wave's 32 windows (the last wave of a block owns 24) ----
+    const int wl = wave * 32 + col;                              // window index inside the block
+    const bool owned = wl < C::windows;
+    const long w = owned ? w0 + wl : n_windows;                  // not owned: masked at the store
+    if (w0 + wave * 32 >= n_windows) return;                     // wave-uniform, after the only barrier
+    const int ml = owned ? wl : C::windows - 1;                  // keep M reads inside the image
+    const ActView v1{M + ml, C::rows, 2, priv + col, kL1 * 32, 32, D::c0};
+    densenet_tail<LARGE>(v1, priv, blob, LY, lane, w, n_windows, p_out, dec_out, mode, threshold);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -342,9 +450,43 @@ int pack(const float* const* t, float* blob) {
     return VAD_OK;
 }
 
+}  // namespace
+
+// The stride-1 kernels use more than 64 KB of dynamic LDS: opt in once per device.
+int ensure_densenet_attrs() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    VAD_HIP_CHECK(hipGetDevice(&dev));
+    VAD_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev]) return VAD_OK;
+    VAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&densenet_stream_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DnStreamCfg<false>::lds_floats * (int)sizeof(float)));
+    VAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&densenet_stream_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DnStreamCfg<true>::lds_floats * (int)sizeof(float)));
+    done[dev] = true;
+    return VAD_OK;
+}
+
+namespace {
+
 template <bool LARGE>
 int launch(const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec, int mode,
            float threshold, hipStream_t st) {
+    if (!wm.rows && wm.stride == kF) {
+        using C = DnStreamCfg<LARGE>;
+        int rc = ensure_densenet_attrs();
+        if (rc != VAD_OK) return rc;
+        const long blocks = (n_windows + C::windows - 1) / C::windows;
+        VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
+        hipLaunchKernelGGL(densenet_stream_kernel<LARGE>, dim3((unsigned)blocks), dim3(C::waves * 64),
+                           (size_t)C::lds_floats * sizeof(float), st, x, n_windows, blob, p, dec, mode, threshold);
+        VAD_HIP_CHECK(hipGetLastError());
+        return VAD_OK;
+    }
     const long blocks = (n_windows + 31) / 32;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
     hipLaunchKernelGGL(densenet_kernel<LARGE>, dim3((unsigned)blocks), dim3(64), 0, st, x, n_windows, wm, blob, p,

@@ -39,6 +39,7 @@ int launch_delta(const float* mfcc_dev, long mfcc_ld, long n_frames, long frames
 
 // One-time per-device opt-in of the model kernels that need more than 64 KB of LDS; defined in rnn.hip.
 int ensure_rnn_attrs();
+int ensure_densenet_attrs();   // the same for the stride-1 DenseNet kernels; defined in densenet.hip
 
 // Where the windows of a model launch start.  rows == nullptr: window w starts at x + w * stride floats
 // (stride 24 = stride-1 windows of a packed feature matrix, 720 = dense (B,30,24) batch).  Otherwise window w
