@@ -67,25 +67,34 @@ def make_models(kind):
     return net, ref
 
 
-def cpu_baseline(kind, budget_s=15.0):
-    """The CPU oracle (float64 numpy MFCC + torch CPU model, batch 2048) on a bounded sample."""
+def cpu_baseline(kind, budget_s=12.0):
+    """The CPU oracle (float64 numpy MFCC + torch CPU model, batch 2048) on a bounded sample: once with torch's
+    default thread count, once (shorter) with a single thread."""
     from oracle import pipeline_ref, synth_ref
     _, ref = make_models(kind)
     minute = synth_ref.synth_frames(0, 2000, seed=1337)            # 1 min = 2000 frames
     pipeline_ref.vad_stream(ref, minute[:400])                     # warm-up
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        pipeline_ref.vad_stream(ref, minute)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or reps >= 200:
-            break
-    hours = reps * 2000 / FRAMES_PER_HOUR
-    return {'value': hours / dt, 'unit': 'audio-hours/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+
+    def leg(budget):
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            pipeline_ref.vad_stream(ref, minute)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or reps >= 200:
+                return reps, dt
+
+    threads = torch.get_num_threads()
+    reps, dt = leg(budget_s)
+    torch.set_num_threads(1)
+    reps1, dt1 = leg(budget_s / 3)
+    torch.set_num_threads(threads)
+    return {'value': reps * 2000 / FRAMES_PER_HOUR / dt, 'unit': 'audio-hours/s', 'cores': threads, 'kind': 'port',
+            'single_thread_value': reps1 * 2000 / FRAMES_PER_HOUR / dt1,
             'sample': '%d x 1 min synthetic audio (2000 frames, 1971 windows each), float64 numpy/scipy MFCC+delta '
-                      'in 166-frame slices + torch CPU %s, batch 2048; %.1f s of CPU work, host has %d CPUs'
-                      % (reps, kind, dt, os.cpu_count())}
+                      'in 166-frame slices + torch CPU %s, batch 2048; %.1f s of CPU work (+ %.1f s single-threaded), '
+                      'host has %d CPUs' % (reps, kind, dt, dt1, os.cpu_count())}
 
 
 def main():
