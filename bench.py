@@ -40,6 +40,12 @@ FRONTEND_BYTES_PER_FRAME = 480 * 2 + 24 * 4          # int16 in, 24 floats out
 FRONTEND_FLOP_PER_FRAME = 64_000                       # 2048-pt rfft + power + mel + DCT + delta
 PEAK_FP32_TFLOPS = 157.3                               # dense fp32 matrix = fp32 vector peak, MI355X
 PEAK_HBM_GBS = 8000.0
+# What the stride-1 GRU/LSTM kernels execute per window (padded 32-row tiles, projection hoisted to once per row):
+# 30 steps x (gate tiles + head tile) x 15 MFMAs x 4096 flop / 32 windows + the row's projection + gate math.
+EXECUTED_FLOP_PER_WINDOW = {
+    'gru_large': 30 * 4 * 15 * 4096 // 32 + 3 * 12 * 4096 // 32 + 30 * 32 * 13,
+    'lstm_large': 30 * 5 * 15 * 4096 // 32 + 4 * 12 * 4096 // 32 + 30 * 32 * 18,
+}
 # HBM bytes per frame from rocprofv3 --pmc passes over this same command at 100 h (12,000,059 frames per launch;
 # profiles/r01_e_bench_pmc_100h.txt): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of coalesced streaming
 # reads at 64 bytes; unscaled, mfcc_kernel's figure would be 0.63x the input it must read) + WRITE_SIZE, KiB -> bytes.  Counters cannot be read from inside this process, so the
@@ -200,6 +206,9 @@ def main():
                       'frac': achieved / PEAK_FP32_TFLOPS,
                       'traffic': None if nn_traffic is None else nn_traffic * n_windows, 'ms_per_launch': nn_ms,
                       'algorithmic_bytes': (24 * 4 + 9) * n_windows,
+                      'executed_flop_per_window': EXECUTED_FLOP_PER_WINDOW.get(args.model),
+                      'frac_executed': None if args.model not in EXECUTED_FLOP_PER_WINDOW else
+                      EXECUTED_FLOP_PER_WINDOW[args.model] * n_windows / (nn_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
                       'flop_per_window': FLOP_PER_WINDOW[args.model], 'windows_per_launch': n_windows,
                       'note': 'achieved = algorithmic (PyTorch-equivalent) flops / time; the stride-1 GRU/LSTM kernel '
                               'projects each feature row once instead of once per window, so it executes ~0.69x of them'}
