@@ -197,3 +197,23 @@ def test_full_size_stream_properties(vad):
     with torch.no_grad():
         y = ref(batch.cpu()).numpy()
     assert np.abs(pb.cpu().numpy() - y).max() <= 1e-5
+
+
+def test_gain_and_shift_properties(vad):
+    """Size-independent properties on a long stream: c1..c12 ignore a gain of 2 (the DCT rows annihilate the
+    log 4 offset), and with the whole stream as one slice the features of a stream that starts one frame
+    later are the same rows shifted by one (except the un-emphasised first row's reach and the delta edge)."""
+    n = 50000
+    stream = vad.synth_stream(0, n + 1, seed=77)
+    quiet = torch.div(stream, 4, rounding_mode='trunc').to(torch.int16)          # headroom for the doubling
+    f1 = vad.mfcc_delta_stream(quiet, n, 166)
+    f2 = vad.mfcc_delta_stream((quiet * 2).to(torch.int16), n, 166)
+    host = quiet.cpu().numpy().reshape(-1, 480)
+    audible = torch.from_numpy(np.convolve((np.abs(host).max(1) > 0).astype(int), np.ones(4, int), 'full')[3:n + 3] > 0).cuda()
+    err = ((f2 - f1).abs() / f1.abs().clamp(min=1.0))[audible]               # frames with any energy in their window
+    assert float(err.max()) <= 2e-4                                          # two fp32 evaluations, each within 1e-4
+    # time shift, single slice
+    a = vad.mfcc_delta_stream(stream, n, 0)
+    b = vad.mfcc_delta_stream(stream[480:], n, 0)
+    assert torch.equal(a[6:n - 2, :12], b[5:n - 3, :12])                     # MFCC rows away from the slice's first frames
+    assert torch.equal(a[8:n - 4, 12:], b[7:n - 5, 12:])                     # deltas two more rows in

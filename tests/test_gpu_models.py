@@ -276,3 +276,27 @@ def test_split_bf16_matrix_modes(vad, kind, mode):
     _decisions_agree(d.cpu().numpy(), y)
     with pytest.raises(ValueError):
         vad.set_matrix_mode('fp8')
+
+
+def test_calls_follow_the_current_stream(vad):
+    """Every entry point launches on the caller's stream: two side streams working on different inputs at
+    the same time give the results of the default stream (the library keeps no mutable device state)."""
+    ref = models_ref.make_model('gru_large')
+    net = _gpu_model(vad, 'gru_large', ref)
+    n = 20000
+    a = vad.synth_stream(0, n, seed=1)
+    b = vad.synth_stream(0, n, seed=2)
+    fa, pa, da = vad.vad_stream(net, a, n)
+    fb, pb, db = vad.vad_stream(net, b, n)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = {}
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            outs['a'] = vad.vad_stream(net, a, n)
+        with torch.cuda.stream(s2):
+            outs['b'] = vad.vad_stream(net, b, n)
+    s1.synchronize()
+    s2.synchronize()
+    assert torch.equal(outs['a'][0], fa) and torch.equal(outs['a'][1], pa) and torch.equal(outs['a'][2], da)
+    assert torch.equal(outs['b'][0], fb) and torch.equal(outs['b'][1], pb) and torch.equal(outs['b'][2], db)

@@ -167,3 +167,14 @@ def test_golden_slices_reproduce():
         np.testing.assert_allclose(d, g['delta'][s], rtol=0, atol=1e-9)
     # the zeroed frames of slice 1 put whole analysis windows into the eps clamp: cepstra vanish there
     assert np.abs(g['mfcc'][1][23:28]).max() < 1e-9
+
+
+def test_gain_invariance_of_c1_to_c12():
+    """Doubling the input adds log 4 to every log filter energy; DCT rows k >= 1 annihilate a constant, so
+    c1..c12 and their deltas do not change (away from the zero-energy clamp)."""
+    rng = np.random.default_rng(8)
+    rows = rng.integers(-8000, 8000, size=(43, 480)).astype(np.int16)
+    _, m1, d1 = mfcc_ref.process_test_frames(rows[3:], rows[:3])
+    _, m2, d2 = mfcc_ref.process_test_frames((2 * rows[3:]).astype(np.int16), (2 * rows[:3]).astype(np.int16))
+    np.testing.assert_allclose(m2, m1, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(d2, d1, rtol=0, atol=1e-9)
