@@ -46,7 +46,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
 constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twiddle tables
 constexpr int kSmemBytes = kWavesPerBlock * kWaveLdsBytes + kTwBytes;
-constexpr int kBlocksPerCu = 3;                              // = waves per SIMD; a block needs 49 KB of LDS
+constexpr int kBlocksPerCu = 3;                              // = waves per SIMD; a block needs 43 KB of LDS
 
 // Where frame g of the launch lives: slice s, frame j inside it.
 struct FramePos {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, kBlocksPerCu) void mfcc_kernel(const int16_t* 
 
     RawFrame raw;
     {
-        // tw1, tw2, twr are the first members of MfccTables, contiguous in this order
+        // tw1 is the first member of MfccTables
         const float4* src = reinterpret_cast<const float4*>(tab);
         float4* dst = reinterpret_cast<float4*>(smem + kWavesPerBlock * kWaveLdsBytes);
         for (int i = threadIdx.x; i < kTwFloat2s / 2; i += 256) dst[i] = src[i];

@@ -101,14 +101,14 @@ constexpr int kPartOffset = kPowFloats;        // float offset of the 2 x 64 mel
 constexpr int kWaveLdsBytes = kExBytes + kFramesPerWave * 32 * 4;
 static_assert((kPartOffset + 128) * 4 <= kExBytes, "power spectrum + partial sums must fit the exchange region");
 
-// Block-shared LDS image of the twiddle tables: tw1[12][64], tw2[15][16], twr[8][64] (the head of MfccTables).
-constexpr int kTw2Offset = 12 * 64;
-constexpr int kTwrOffset = kTw2Offset + 15 * 16;
-constexpr int kTwFloat2s = kTwrOffset + 8 * 64;
+// Block-shared LDS image of the W1024 twiddles tw1[12][64] (the head of MfccTables); the other two sets
+// live in registers.
+constexpr int kTwFloat2s = 12 * 64;
 
 // Loop-invariant per-lane constants that stay in registers (the twiddles do not: see frame_energies).
 struct LaneConst {
-    float2 tw2[15];                           // W256^(c q1) of this lane's c: the one twiddle set that fits the registers
+    float2 tw2[15];                           // W256^(c q1) of this lane's c  } the twiddle sets that fit the
+    float2 twr[8];                            // W2048^(k1 + 4 q1 + 64 jj)       } registers at 3 waves per SIMD
     int run_start, run_count;
     float run_inv, run_w0, run_f0;
     int rise_first, rise_n, fall_first, fall_n;
@@ -118,6 +118,8 @@ struct LaneConst {
 __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* __restrict__ tab, int lane) {
 #pragma unroll
     for (int k = 0; k < 15; ++k) K.tw2[k] = tab->tw2[k][lane & 15];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) K.twr[j] = tab->twr[j][lane];
     K.run_start = tab->run_start[lane];
     K.run_count = tab->run_count[lane];
     const float b0 = (float)tab->run_b0[lane], b1 = (float)tab->run_b1[lane];
@@ -234,7 +236,7 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         if (lane == 0) b = v[(16 - jj) & 15];
         const float2 e = make_float2(a.x + b.x, a.y - b.y);
         const float2 o = make_float2(a.x - b.x, a.y + b.y);
-        const float2 t = cmul(tws[kTwrOffset + jj * 64 + lane], o);
+        const float2 t = cmul(K.twr[jj], o);
         const float ar = e.x + t.y, ai = e.y - t.x;                       // E - iT
         const float br = e.x - t.y, bi = e.y + t.x;                       // E + iT
         const int k = K.kbase + 64 * jj;
