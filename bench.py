@@ -47,10 +47,10 @@ EXECUTED_FLOP_PER_WINDOW = {
     'lstm_large': 30 * 5 * 15 * 4096 // 32 + 4 * 12 * 4096 // 32 + 30 * 32 * 18,
 }
 # HBM bytes per frame from rocprofv3 --pmc passes over this same command at 100 h (12,000,059 frames per launch;
-# profiles/r01_e_bench_pmc_100h.txt): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of coalesced streaming
+# profiles/r01_h_bench_pmc_100h.txt): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of coalesced streaming
 # reads at 64 bytes; unscaled, mfcc_kernel's figure would be 0.63x the input it must read) + WRITE_SIZE, KiB -> bytes.  Counters cannot be read from inside this process, so the
 # per-launch figure is this measured per-frame constant times the frames of the launch.
-_KIB_PER_LAUNCH = {'frontend': 2 * (7073920 + 702018) + 750000 + 755859,      # mfcc_kernel + delta_kernel
+_KIB_PER_LAUNCH = {'frontend': 2 * (7073810 + 702013) + 750000 + 755859,      # mfcc_kernel + delta_kernel
                    'gru_large': 2 * 633401 + 105469}                            # rnn_stream_kernel<GRU, large>
 TRAFFIC_BYTES_PER_FRAME = {k: v * 1024 / 12000059 for k, v in _KIB_PER_LAUNCH.items()}
 
