@@ -150,7 +150,7 @@ def test_large_stream_properties(vad):
 
 
 def test_full_size_stream_properties(vad):
-    """BASELINE configuration size: 100 h = 12 M frames (11.5 GB of int16) through the whole path.
+    """Benchmark configuration size: 100 h = 12 M frames (11.5 GB of int16) through the whole path.
     The oracle cannot sweep this, so the checks are size-independent properties: determinism,
     slice independence (any slice recomputed alone reproduces the big run bit for bit), window
     independence (any window recomputed from a materialised batch reproduces its posterior bit for

@@ -1,4 +1,4 @@
-// Device-side building blocks of the GRU / LSTM window models, shared by rnn.hip and fused.hip.
+// Device-side building blocks of the GRU / LSTM window models (kernels and launch code: rnn.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
