@@ -22,8 +22,8 @@
 // is left in LDS for the mel stage.
 //
 // Occupancy is the design constraint: a wave stalls on its own LDS exchanges, so the kernel keeps three
-// waves per SIMD (<= 168 VGPRs, 49 KB of LDS per 4-wave block): the input is read straight from global
-// memory (no block staging buffer), two of the three twiddle sets live in a block-shared LDS table.
+// waves per SIMD (<= 168 VGPRs, 24 KB of LDS per 2-wave block): the input is read straight from global
+// memory (no block staging buffer), one of the three twiddle sets lives in a block-shared LDS table.
 //
 // Precision: FFT, power and mel sums in fp32; filter energies, log and DCT in
 // fp64 (26 logs and 312 fused multiply-adds per frame), because an fp32 log of
@@ -42,11 +42,12 @@ using namespace fe;
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 2;                            // small blocks schedule best (measured 2 < 3 < 4 << 6 waves)
+constexpr int kThreads = 64 * kWavesPerBlock;
 constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
 constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twiddle tables
 constexpr int kSmemBytes = kWavesPerBlock * kWaveLdsBytes + kTwBytes;
-constexpr int kBlocksPerCu = 3;                              // = waves per SIMD; a block needs 43 KB of LDS
+constexpr int kBlocksPerCu = 12 / kWavesPerBlock;            // three waves per SIMD; a block needs 24 KB of LDS
 
 // Where frame g of the launch lives: slice s, frame j inside it.
 struct FramePos {
@@ -54,11 +55,11 @@ struct FramePos {
     long j;
 };
 
-// grid: one block per 16 consecutive frames of the launch (slices are not padded to blocks: a block may
-// straddle slices, each frame finds its own slice).  Wave w takes frames w, w+4, w+8, w+12 of the block, so
-// the four waves walk neighbouring rows at the same time and the 4x re-read of every input row (hop 480,
+// grid: one block per 8 consecutive frames of the launch (slices are not padded to blocks: a block may
+// straddle slices, each frame finds its own slice).  Wave w takes frames w, w+2, w+4, w+6 of the block, so
+// the waves walk neighbouring rows at the same time and the 4x re-read of every input row (hop 480,
 // window 1920, plus the pre-emphasis lag) is served by the caches.
-__global__ __launch_bounds__(256, kBlocksPerCu) void mfcc_kernel(const int16_t* __restrict__ in,
+__global__ __launch_bounds__(kThreads, kBlocksPerCu) void mfcc_kernel(const int16_t* __restrict__ in,
                                                                  const MfccTables* __restrict__ tab, long n_frames,
                                                                  long frames_per_slice, long slice_stride,
                                                                  float* __restrict__ out, long out_ld) {
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, kBlocksPerCu) void mfcc_kernel(const int16_t* 
         // tw1 is the first member of MfccTables
         const float4* src = reinterpret_cast<const float4*>(tab);
         float4* dst = reinterpret_cast<float4*>(smem + kWavesPerBlock * kWaveLdsBytes);
-        for (int i = threadIdx.x; i < kTwFloat2s / 2; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kTwFloat2s / 2; i += kThreads) dst[i] = src[i];
         __syncthreads();
     }
 
@@ -283,7 +284,7 @@ extern "C" int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, i
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const long blocks = (n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many frames for one launch");
-    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(256), 0, st, frames_dev, g_tables[dev], n_frames,
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, frames_dev, g_tables[dev], n_frames,
                        (long)frames_per_slice, (long)slice_stride, mfcc_dev, (long)mfcc_ld);
     VAD_HIP_CHECK(hipGetLastError());
     return launch_delta(mfcc_dev, mfcc_ld, n_frames, frames_per_slice, delta_dev, delta_ld, 0, n_frames, st);
