@@ -6,6 +6,7 @@ call fails, a ``VadError`` is raised -- there is no CPU fallback.
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -50,7 +51,14 @@ def build(verbose=False):
            '-I' + INCLUDE, '-I' + CSRC, '-o', LIB_PATH] + srcs
     if verbose:
         print(' '.join(cmd))
-    subprocess.run(cmd, check=True)
+    # the device-only feature switch makes the host pass of every source print an 'ignoring feature' note
+    proc = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    noise = "'-packed-fp32-ops' is not a recognized feature for this target"
+    for line in proc.stderr.splitlines():
+        if noise not in line:
+            print(line, file=sys.stderr)
+    if proc.returncode != 0:
+        raise subprocess.CalledProcessError(proc.returncode, cmd)
     return LIB_PATH
 
 

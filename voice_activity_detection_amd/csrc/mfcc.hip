@@ -47,7 +47,7 @@ constexpr int kThreads = 64 * kWavesPerBlock;
 constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
 constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twiddle tables
 constexpr int kSmemBytes = kWavesPerBlock * kWaveLdsBytes + kTwBytes;
-constexpr int kBlocksPerCu = 12 / kWavesPerBlock;            // three waves per SIMD; a block needs 24 KB of LDS
+constexpr int kWavesPerSimd = 3;                             // register budget 168; a block needs 24 KB of LDS
 
 // Where frame g of the launch lives: slice s, frame j inside it.
 struct FramePos {
@@ -59,7 +59,7 @@ struct FramePos {
 // straddle slices, each frame finds its own slice).  Wave w takes frames w, w+2, w+4, w+6 of the block, so
 // the waves walk neighbouring rows at the same time and the 4x re-read of every input row (hop 480,
 // window 1920, plus the pre-emphasis lag) is served by the caches.
-__global__ __launch_bounds__(kThreads, kBlocksPerCu) void mfcc_kernel(const int16_t* __restrict__ in,
+__global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int16_t* __restrict__ in,
                                                                  const MfccTables* __restrict__ tab, long n_frames,
                                                                  long frames_per_slice, long slice_stride,
                                                                  float* __restrict__ out, long out_ld) {
