@@ -139,7 +139,7 @@ def main():
 
     import voice_activity_detection_amd as pkg
     from voice_activity_detection_amd.sharding import shard_plan
-    pkg.lib()
+    pkg.init()
     pkg.set_matrix_mode(args.matrix_mode)
     net, _ = make_models(args.model)
 

@@ -300,3 +300,8 @@ def test_calls_follow_the_current_stream(vad):
     s2.synchronize()
     assert torch.equal(outs['a'][0], fa) and torch.equal(outs['a'][1], pa) and torch.equal(outs['a'][2], da)
     assert torch.equal(outs['b'][0], fb) and torch.equal(outs['b'][1], pb) and torch.equal(outs['b'][2], db)
+
+
+def test_init_is_idempotent(vad):
+    vad.init()
+    vad.init()

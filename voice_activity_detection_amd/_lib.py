@@ -119,6 +119,12 @@ def lib():
     return L
 
 
+def init():
+    """vad_init() on the current device: constant tables and LDS opt-ins, the two one-time steps that
+    cannot happen inside a HIP graph capture.  Optional otherwise (the first call that needs them does it)."""
+    check(lib().vad_init())
+
+
 def check(rc):
     if rc != 0:
         raise VadError('libvad_amd call failed (%d): %s' % (rc, lib().vad_last_error().decode()))
