@@ -305,3 +305,27 @@ def test_calls_follow_the_current_stream(vad):
 def test_init_is_idempotent(vad):
     vad.init()
     vad.init()
+
+
+def test_path_is_capturable_in_a_hip_graph(vad):
+    """After init() the two launches of a step allocate nothing and synchronise nothing, so the step can be
+    captured once and replayed: the replay on new audio equals a direct run."""
+    ref = models_ref.make_model('gru_large')
+    net = _gpu_model(vad, 'gru_large', ref)
+    n = 166 * 60
+    vad.init()
+    stream = vad.synth_stream(0, n, seed=3)
+    ws = vad.StreamWorkspace(n, stream.device)
+    vad.vad_stream(net, stream, n, workspace=ws)                 # packs the weights outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        vad.mfcc_delta_stream(stream, n, 166, out=ws.feat)
+        net.score(ws.feat, window_stride=24, n_windows=n - 29, out=ws.p, decisions=ws.decision)
+    stream.copy_(vad.synth_stream(0, n, seed=4))                 # new audio in the captured buffer
+    g.replay()
+    torch.cuda.synchronize()
+    p_graph, d_graph, f_graph = ws.p.clone(), ws.decision.clone(), ws.feat.clone()
+    ws2 = vad.StreamWorkspace(n, stream.device)
+    vad.vad_stream(net, vad.synth_stream(0, n, seed=4), n, workspace=ws2)
+    assert torch.equal(f_graph, ws2.feat) and torch.equal(p_graph, ws2.p) and torch.equal(d_graph, ws2.decision)
