@@ -119,16 +119,23 @@ __global__ __launch_bounds__(256, 2) void rnn_kernel(const float* __restrict__ x
 // ---------------------------------------------------------------------------------------------
 // stride-1 windows over a packed (F, 24) matrix, input projection hoisted per row
 
-template <bool LSTM>
-struct StreamCfg {
+template <bool LSTM, int WAVES>
+struct StreamGeom {
     static constexpr int G = LSTM ? 4 : 3;
-    static constexpr int waves = LSTM ? 7 : 8;                  // LDS-limited: one block per CU
-    static constexpr int windows = waves * kWindowsPerWave;     // 224 / 256 windows per block
+    static constexpr int waves = WAVES;
+    static constexpr int windows = waves * kWindowsPerWave;     // windows per block
     static constexpr int tiles = waves + 1;                     // 32-row tiles covering windows + 29 rows
     static constexpr int rs = G * 32 + 4;                       // row stride in floats: 100 / 132, keeps
                                                                 // ds_read_b128 of 16 lanes on distinct banks
     static constexpr int gi_floats = tiles * 32 * rs;
-    static constexpr int lds_floats = gi_floats + G * kHk * 64 + 4 * 2 * 16;
+};
+
+// One block per CU (LDS-limited: the projections of 8 waves take 115 KB (GRU) / 152 KB (LSTM)), 8 waves = 2 per
+// SIMD.  The recurrent A operands are loop-invariant (45 / 60 per lane): they are read from the weight blob and
+// stay in registers instead of taking LDS the LSTM does not have.
+template <bool LSTM>
+struct StreamCfg : StreamGeom<LSTM, 8> {
+    static constexpr int lds_floats = StreamGeom<LSTM, 8>::gi_floats + 4 * 2 * 16;
 };
 
 template <bool LSTM, bool LARGE, int KS>
@@ -140,9 +147,9 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
     extern __shared__ __align__(16) float lds[];
     const NetLayout L = net_layout(LSTM, LARGE);
     float* gi = lds;                                             // [tiles * 32 rows][rs]
-    float* a_hh = lds + C::gi_floats;
-    float* cb = a_hh + G * kHk * 64;
-    for (int i = threadIdx.x; i < G * kHk * 64 + 4 * 2 * 16; i += C::waves * 64) a_hh[i] = blob[L.a_hh + i];
+    float* cb = lds + C::gi_floats;
+    for (int i = threadIdx.x; i < 4 * 2 * 16; i += C::waves * 64) cb[i] = blob[L.cb + i];
+    const float* a_hh = blob + L.a_hh;
 
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -206,12 +213,13 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
 // The input projection (1/30 of the matrix work) stays on the float32 MFMA.
 
 template <bool LSTM>
-struct SplitCfg : StreamCfg<LSTM> {
-    static constexpr int lds_floats = StreamCfg<LSTM>::gi_floats + StreamCfg<LSTM>::G * kSplitTile + 4 * 2 * 16;
+struct SplitCfg : StreamGeom<LSTM, LSTM ? 7 : 8> {
+    using B = StreamGeom<LSTM, LSTM ? 7 : 8>;
+    static constexpr int lds_floats = B::gi_floats + B::G * kSplitTile + 4 * 2 * 16;
 };
 
 template <bool LSTM, bool LARGE, int TERMS>
-__global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_split_kernel(
+__global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_kernel(
     const float* __restrict__ feat, long n_windows, const float* __restrict__ blob, float* __restrict__ p_out,
     uint8_t* __restrict__ dec_out, int mode, float threshold) {
     using C = SplitCfg<LSTM>;
