@@ -329,3 +329,20 @@ def test_path_is_capturable_in_a_hip_graph(vad):
     ws2 = vad.StreamWorkspace(n, stream.device)
     vad.vad_stream(net, vad.synth_stream(0, n, seed=4), n, workspace=ws2)
     assert torch.equal(f_graph, ws2.feat) and torch.equal(p_graph, ws2.p) and torch.equal(d_graph, ws2.decision)
+
+
+@pytest.mark.parametrize('hidden', [90, 40])
+def test_sampled_windows_wide_gru(vad, hidden):
+    ref = models_ref.make_model('gru_large', hidden=hidden)
+    net = vad.Net(large=True, lstm=False, hidden=hidden)
+    net.load_state_dict(ref.state_dict())
+    rng = np.random.default_rng(hidden)
+    feat = torch.tensor(rng.normal(0, 8, size=(300, 24)).astype(np.float32)).cuda()
+    rows = rng.integers(0, 271, size=77)
+    p, d = net.score_rows(feat, rows)
+    batch = torch.stack([feat[r: r + 30] for r in rows]).contiguous()
+    pb, db = net.score(batch)
+    assert torch.equal(p, pb) and torch.equal(d, db)
+    with torch.no_grad():
+        y = ref(batch.cpu()).numpy()
+    assert np.abs(p.cpu().numpy() - y).max() <= ATOL
