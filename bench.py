@@ -55,22 +55,37 @@ _KIB_PER_LAUNCH = {'frontend': 2 * (7073810 + 702013) + 750000 + 755859,      # 
 TRAFFIC_BYTES_PER_FRAME = {k: v * 1024 / 12000059 for k, v in _KIB_PER_LAUNCH.items()}
 
 
-def make_models(kind):
+def make_net(kind):
+    """The product model with seeded random weights (no checkpoints ship): torch's default initialisation of
+    the modules under the reference's seed (core/train.py:56), BatchNorm statistics perturbed away from the
+    identity.  Nothing from oracle/ is involved in the measured path."""
     import voice_activity_detection_amd as pkg
-    from oracle import models_ref
-    if kind == 'gru_h90':                              # no class in the reference: torch.nn.GRU(24, 90) + heads
-        ref = models_ref.make_model('gru_large', hidden=90)
-        net = pkg.Net(large=True, lstm=False, hidden=90)
-        net.load_state_dict(ref.state_dict())
-        return net, ref
-    ref = models_ref.make_model(kind)                  # seeded random weights (no checkpoints ship)
+    torch.manual_seed(1337)
+    if kind == 'gru_h90':                              # no class in the reference: GRU(24, 90) + the same heads
+        return pkg.Net(large=True, lstm=False, hidden=90)
     if kind.startswith('densenet'):
         net = pkg.DenseNet(large=kind.endswith('large'))
-    else:
-        rnn, size = kind.split('_')
-        net = pkg.Net(large=(size == 'large'), lstm=(rnn == 'lstm'))
-    net.load_state_dict(ref.state_dict())
-    return net, ref
+        g = torch.Generator().manual_seed(1338)
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    n = m.num_features
+                    m.running_mean.copy_(torch.randn(n, generator=g) * 0.5)
+                    m.running_var.copy_(torch.rand(n, generator=g) * 1.5 + 0.5)
+                    m.weight.copy_(torch.rand(n, generator=g) + 0.5)
+                    m.bias.copy_(torch.randn(n, generator=g) * 0.3)
+        return net
+    rnn, size = kind.split('_')
+    return pkg.Net(large=(size == 'large'), lstm=(rnn == 'lstm'))
+
+
+def make_models(kind):
+    """(product model, CPU oracle model with the same weights): for the checker-side tools and the CPU baseline."""
+    from oracle import models_ref
+    net = make_net(kind)
+    ref = models_ref.make_model('gru_large', hidden=90) if kind == 'gru_h90' else models_ref.make_model(kind)
+    ref.load_state_dict(net.state_dict())
+    return net, ref.eval()
 
 
 def cpu_baseline(kind, budget_s=12.0):
@@ -141,7 +156,7 @@ def main():
     from voice_activity_detection_amd.sharding import shard_plan
     pkg.init()
     pkg.set_matrix_mode(args.matrix_mode)
-    net, _ = make_models(args.model)
+    net = make_net(args.model)
 
     frames_per_gpu = int(round(args.hours * FRAMES_PER_HOUR))
     # contiguous slice-aligned shard of one stream; the rank re-creates its own lead-in and halo,

@@ -3,13 +3,13 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import voice_activity_detection_amd as pkg
-from bench import make_models
+from bench import make_net
 
 kind = sys.argv[1] if len(sys.argv) > 1 else 'gru_large'
 mode = sys.argv[2] if len(sys.argv) > 2 else 'f32'
 hours = float(sys.argv[3]) if len(sys.argv) > 3 else 50.0
 n = int(hours * 120000)
-net, _ = make_models(kind)
+net = make_net(kind)
 pkg.set_matrix_mode(mode)
 feat = torch.randn(n, 24, device='cuda') * 8
 p = torch.empty(n - 29, 2, device='cuda')

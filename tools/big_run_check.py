@@ -4,12 +4,12 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import voice_activity_detection_amd as pkg
-from bench import make_models
+from bench import make_net
 
 hours = float(sys.argv[1]) if len(sys.argv) > 1 else 1250.0
 kind = sys.argv[2] if len(sys.argv) > 2 else 'gru_large'
 n = int(hours * 120000) // 166 * 166 + 77                       # ragged last slice
-net, _ = make_models(kind)
+net = make_net(kind)
 print('frames', n, 'audio GB', (n + 3) * 960 / 1e9, flush=True)
 stream = pkg.synth_stream(0, n, seed=1337)
 ws = pkg.StreamWorkspace(n, stream.device)

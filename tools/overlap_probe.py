@@ -3,13 +3,13 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import voice_activity_detection_amd as pkg
-from bench import make_models
+from bench import make_net
 
 hours = float(sys.argv[1]) if len(sys.argv) > 1 else 100.0
 chunks = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 mode = sys.argv[3] if len(sys.argv) > 3 else 'f32'
 pkg.set_matrix_mode(mode)
-net, _ = make_models('gru_large')
+net = make_net("gru_large")
 n = int(hours * 120000) // (166 * chunks) * (166 * chunks)
 stream = pkg.synth_stream(0, n, seed=1337)
 feat = torch.empty(n, 24, device='cuda')
