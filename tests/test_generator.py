@@ -79,3 +79,17 @@ def test_skip_single_class():
     assert g.get_batch(0, skip_single_class=True) == ([], [])
     rows, y = g.get_batch_rows(0, skip_single_class=True)
     assert rows.size == 0 and y.size == 0
+
+
+def test_slice_list_follows_the_reference_loop():
+    """core/process_data.py:190-195 and the skip rule at :214-217, written out."""
+    from voice_activity_detection_amd.process_data import recording_slices
+    for l in (0, 33, 34, 166, 167, 199, 200, 332, 333, 1000, 1029, 1030):
+        pos, ref = 0, []
+        while pos + 33 < l:
+            s = (pos, pos + 166)
+            ref.append(s)
+            pos = s[1]
+        ref = [s for s in ref if (np.array(s) < l).all()]
+        assert recording_slices(l) == ref
+    assert recording_slices(167) == [(0, 166)] and recording_slices(166) == []

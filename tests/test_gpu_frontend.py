@@ -217,3 +217,24 @@ def test_gain_and_shift_properties(vad):
     b = vad.mfcc_delta_stream(stream[480:], n, 0)
     assert torch.equal(a[6:n - 2, :12], b[5:n - 3, :12])                     # MFCC rows away from the slice's first frames
     assert torch.equal(a[8:n - 4, 12:], b[7:n - 5, 12:])                     # deltas two more rows in
+
+
+def test_process_test_data_matches_the_slice_loop(vad):
+    """One device call for a recording against the reference's loop of per-slice calls (oracle side)."""
+    n = 166 * 3 + 50
+    fr = synth_ref.synth_frames(0, n, seed=31)
+    labels = (np.arange(n) // 40 % 2).astype(np.int8)
+    out = vad.process_test_data(fr, labels)
+    assert out['count'] == 166 * 3
+    pos = 0
+    for s in vad.recording_slices(n):
+        align = np.zeros((3, 480), np.int16) if pos == 0 else fr[pos - 3: pos]
+        _, rm, rd = mfcc_ref.process_test_frames(fr[s[0]: s[1]], align)
+        assert_feat_close(out['mfcc'][pos: pos + 166], rm.astype(np.float32), 'mfcc slice at %d' % pos)
+        assert_feat_close(out['delta'][pos: pos + 166], rd.astype(np.float32), 'delta slice at %d' % pos)
+        pos += 166
+    np.testing.assert_array_equal(out['frames'][:pos], fr[:pos])
+    np.testing.assert_array_equal(out['labels'][:pos], labels[:pos])
+    assert not out['mfcc'][pos:].any() and not out['frames'][pos:].any()
+    assert out['mfcc'].dtype == np.float32 and out['labels'].dtype == np.int8
+    assert vad.process_test_data(fr[:100], labels[:100])['count'] == 0

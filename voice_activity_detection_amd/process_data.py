@@ -12,6 +12,7 @@ plus device-resident batch forms that the per-slice Python loop of
 * ``mfcc_delta_slices``  a batch of independently stored slices
 * ``mfcc_delta_stream``  one contiguous stream cut into fixed-length slices
 * ``overlay_device``     the int16 noise/speech mix of add_noise on device tensors
+* ``process_test_data``  the whole per-slice loop of a recording as one call
 
 All arithmetic runs in ``vad_mfcc_delta_f32`` / ``vad_overlay_i16`` of libvad_amd.so.
 """
@@ -21,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .common import ALIGN_FRAMES, FRAME_SIZE, SLICE_MAX
+from .common import ALIGN_FRAMES, FRAME_SIZE, SLICE_MAX, SLICE_MIN
 
 
 def _device():
@@ -109,6 +110,47 @@ def process_test_frames(data_frames, align_frames):
     dev = torch.from_numpy(aligned).to(_device()).unsqueeze(0)
     mfcc, delta = mfcc_delta_slices(dev)
     return frames, mfcc[0].cpu().numpy().astype(np.float64), delta[0].cpu().numpy().astype(np.float64)
+
+
+def recording_slices(n_frames):
+    """The slices process_test_data cuts a recording of ``n_frames`` labelled frames into
+    (core/process_data.py:190-195, 214-217): consecutive ``(start, start + SLICE_MAX)`` pairs while
+    ``start + SLICE_MIN < n_frames``, of which those whose end is not below ``n_frames`` are skipped."""
+    pos, slices = 0, []
+    while pos + SLICE_MIN < n_frames:
+        s = (pos, pos + SLICE_MAX)
+        pos = s[1]
+        if s[0] < n_frames and s[1] < n_frames:
+            slices.append(s)
+    return slices
+
+
+def process_test_data(frames, labels):
+    """In-memory form of the slice loop of process_test_data (core/process_data.py:186-246), which calls
+    process_test_frames once per 166-frame slice with the previous slice's last 3 frames as alignment rows
+    and stores the rows in HDF5 datasets.  Here the whole recording takes ONE device call; the result is a
+    dict of arrays laid out like the datasets the loop fills: ``frames`` (int16), ``mfcc`` / ``delta``
+    (float32, as stored at :204-205), ``labels`` (int8), each ``len(frames)`` rows of which the first
+    ``count`` are written (the reference drops the ragged end of the recording)."""
+    fr = _as_frames(frames, 'frames')
+    lab = np.asarray(labels)
+    total = len(fr)
+    if len(lab) != total:
+        raise ValueError('labels has %d entries, frames %d' % (len(lab), total))
+    slices = recording_slices(total)
+    count = slices[-1][1] if slices else 0
+    out = {'frames': np.zeros((total, FRAME_SIZE), np.int16), 'mfcc': np.zeros((total, 12), np.float32),
+           'delta': np.zeros((total, 12), np.float32), 'labels': np.zeros((total,), np.int8), 'count': count}
+    if count:
+        dev = _device()
+        stream = torch.zeros((count + ALIGN_FRAMES) * FRAME_SIZE, dtype=torch.int16, device=dev)   # zero lead-in, :227
+        stream[ALIGN_FRAMES * FRAME_SIZE:] = torch.from_numpy(fr[:count].reshape(-1)).to(dev)
+        feat = mfcc_delta_stream(stream, count, SLICE_MAX).cpu().numpy()
+        out['frames'][:count] = fr[:count]
+        out['mfcc'][:count] = feat[:, :12]
+        out['delta'][:count] = feat[:, 12:]
+        out['labels'][:count] = lab[:count]
+    return out
 
 
 def overlay_device(noise_dev, speech_dev, gain_during_overlay=None, out=None):
