@@ -16,7 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import models_ref, pipeline_ref, synth_ref
-from voice_activity_detection_amd.sharding import (gather_posteriors, shard_plan, shard_range,
+from voice_activity_detection_amd.sharding import (all_gather_posteriors, gather_posteriors, shard_plan, shard_range,
                                                    window_owner_ranges)
 
 N_FRAMES = 166 * 5 + 40
@@ -49,6 +49,8 @@ def _worker(rank, world, port, out_path):
     p = pipeline_ref.score_windows(net, pipeline_ref.windows(feat))[:nw]
     assert len(p) == nw and w0 == min(first, N_FRAMES - 29)
     full = gather_posteriors(torch.from_numpy(p), world, dist)
+    everywhere = all_gather_posteriors(torch.from_numpy(p), world, dist)       # the collective form, on every rank
+    assert torch.equal(everywhere, full)
     if rank == 0:
         np.save(out_path, full.numpy())
     dist.barrier()

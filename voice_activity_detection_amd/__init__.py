@@ -14,7 +14,7 @@ from . import metrics
 from .generator import DataGenerator
 from .metrics import fix_frr, roc_curve, threshold_sweep
 from .stream import StreamWorkspace, vad_stream
-from .sharding import HALO_FRAMES, gather_posteriors, shard_plan, shard_range, window_owner_ranges
+from .sharding import HALO_FRAMES, all_gather_posteriors, gather_posteriors, shard_plan, shard_range, window_owner_ranges
 from .synth import synth_audio, synth_stream
 
 __all__ = ['VadError', 'build', 'init', 'lib', 'Net', 'DenseNet', 'MODEL_STACK', 'set_matrix_mode', 'process_test_frames', 'process_test_data', 'recording_slices', 'add_noise',
