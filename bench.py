@@ -8,57 +8,105 @@ posterior + decision per window, all left in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--hours H] [--model gru_large]
 
-For N > 1 the driver launches one rank per GPU through torch.distributed.run;
-every rank scores its own contiguous shard of the stream (weak scaling, no
-data-path collective); the timed region is bracketed by a barrier and the
-slowest rank's time is used.  Rank 0 prints ONE JSON line.
+For N > 1 there is one rank per GPU.  Started under torch.distributed.run the
+process is a rank; started plainly (`python bench.py --gpus N`) it starts the N
+ranks itself as child processes, before anything touches a GPU, relays rank 0's
+JSON line and exits with the children's status.  Every rank scores its own
+contiguous shard of the stream (weak scaling, no data-path collective); the
+timed region is bracketed by a barrier and the slowest rank's time is used.
+Rank 0 prints ONE JSON line: the headline workload (GRU-30k, 100 h per GPU)
+plus, under "configs", the other model configurations timed the same way.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FRAMES_PER_HOUR = 120000          # 3600 s / 0.03 s
-# Algorithmic work per unit, PyTorch-equivalent operation counts.
-FLOP_PER_WINDOW = {               # per 30 x 24 window
-    'gru_large': 30 * 24 * 90 * 2 + 30 * 30 * 90 * 2 + 30 * 30 * 12 + 900 * 26 * 2 + 26 * 2 * 2,
-    'gru_small': 30 * 24 * 90 * 2 + 30 * 30 * 90 * 2 + 30 * 30 * 12 + 900 * 2 * 2,
-    'lstm_large': 30 * 24 * 120 * 2 + 30 * 30 * 120 * 2 + 30 * 30 * 15 + 900 * 26 * 2 + 26 * 2 * 2,
-    'lstm_small': 30 * 24 * 120 * 2 + 30 * 30 * 120 * 2 + 30 * 30 * 15 + 900 * 2 * 2,
-    'gru_h90': 30 * 24 * 270 * 2 + 30 * 90 * 270 * 2 + 30 * 90 * 12 + 2700 * 26 * 2 + 26 * 2 * 2,   # enlarged GRU, ~100k params
-    'densenet': 103_000,
-    'densenet_large': 262_000,
-}
+T, F = 30, 24                     # steps per window, features per row
+PEAK_FP32_TFLOPS = 157.3          # dense fp32 matrix = fp32 vector (FMA) peak, MI355X
+PEAK_HBM_GBS = 8000.0
+SIMDS = 256 * 4
+VALU_ISSUE_CYCLES = 2.0           # a wave64 vector instruction occupies its SIMD-32 for 2 cycles
 FRONTEND_BYTES_PER_FRAME = 480 * 2 + 24 * 4          # int16 in, 24 floats out
 FRONTEND_FLOP_PER_FRAME = 64_000                       # 2048-pt rfft + power + mel + DCT + delta
-PEAK_FP32_TFLOPS = 157.3                               # dense fp32 matrix = fp32 vector peak, MI355X
-PEAK_HBM_GBS = 8000.0
-# What the stride-1 GRU/LSTM kernels execute per window (padded 32-row tiles, projection hoisted to once per row):
-# 30 steps x (gate tiles + head tile) x 15 MFMAs x 4096 flop / 32 windows + the row's projection + gate math.
-EXECUTED_FLOP_PER_WINDOW = {
-    'gru_large': 30 * 4 * 15 * 4096 // 32 + 3 * 12 * 4096 // 32 + 30 * 32 * 13,
-    'lstm_large': 30 * 5 * 15 * 4096 // 32 + 4 * 12 * 4096 // 32 + 30 * 32 * 18,
-}
-# HBM bytes per frame from rocprofv3 --pmc passes over this same command at 100 h (12,000,059 frames per launch;
-# profiles/r01_h_bench_pmc_100h.txt): 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of coalesced streaming
-# reads at 64 bytes; unscaled, mfcc_kernel's figure would be 0.63x the input it must read) + WRITE_SIZE, KiB -> bytes.  Counters cannot be read from inside this process, so the
-# per-launch figure is this measured per-frame constant times the frames of the launch.
-_KIB_PER_LAUNCH = {'frontend': 2 * (7073810 + 702013) + 750000 + 755859,      # mfcc_kernel + delta_kernel
-                   'gru_large': 2 * 633401 + 105469}                            # rnn_stream_kernel<GRU, large>
-TRAFFIC_BYTES_PER_FRAME = {k: v * 1024 / 12000059 for k, v in _KIB_PER_LAUNCH.items()}
+RESULT_BYTES_PER_WINDOW = 9                            # 2 float posteriors + 1 decision byte
+MODELS = ['gru_large', 'gru_small', 'lstm_large', 'lstm_small', 'gru_h90', 'densenet', 'densenet_large']
 
+
+def _rnn_flops(gates, hidden, head_rows, gate_ops):
+    """(flop per window with the input projection done once per feature row, PyTorch-equivalent flop per window).
+    Stride-1 windows share their rows, so W_ih x_row is algorithmically needed once per row = once per window
+    of the stream; a framework that scores (B,30,24) batches computes it 30 times per window."""
+    proj = F * gates * hidden * 2
+    rest = T * hidden * gates * hidden * 2 + T * hidden * gate_ops + T * hidden * head_rows * 2 + \
+        (head_rows * 2 * 2 if head_rows > 2 else 0)
+    return proj + rest, T * proj + rest
+
+
+def _densenet_flops(c0, layers, growth):
+    """The same pair for DenseNet: the stem convolution (K = 24 x 6) is a property of the feature row and is
+    algorithmically needed once per row; a batch framework evaluates it at 10 positions per window."""
+    c1 = c0 + layers * growth
+    stem = c0 * F * 6 * 2
+    dense = sum((c0 + i * growth) * growth * 3 * 2 for i in range(layers))
+    rest = dense * 5 + c1 * c0 * 2 * 5 + dense * 2 + c1 * c1 * 2 * 2 + c1 * 2 * 2
+    return stem + rest, 10 * stem + rest
+
+
+FLOP_PER_WINDOW = {               # model -> (algorithmic for stride-1 windows, PyTorch-equivalent per (30,24) window)
+    'gru_large': _rnn_flops(3, 30, 26, 12),
+    'gru_small': _rnn_flops(3, 30, 2, 12),
+    'lstm_large': _rnn_flops(4, 30, 26, 15),
+    'lstm_small': _rnn_flops(4, 30, 2, 15),
+    'gru_h90': _rnn_flops(3, 90, 26, 12),          # enlarged GRU, ~100k parameters
+    'densenet': _densenet_flops(24, 6, 3),
+    'densenet_large': _densenet_flops(48, 8, 4),
+}
+# the kernel that scores stride-1 windows of each model, as rocprofv3 names it (template arguments included)
+MODEL_KERNEL = {'gru_large': 'rnn_stream_kernel<false, true, 15>', 'gru_small': 'rnn_stream_kernel<false, false, 15>',
+                'lstm_large': 'rnn_stream_kernel<true, true, 15>', 'lstm_small': 'rnn_stream_kernel<true, false, 15>',
+                'gru_h90': 'gru_wide_kernel<true, 3>',
+                'densenet': 'densenet_stream_kernel<false>', 'densenet_large': 'densenet_stream_kernel<true>'}
+
+
+# ---------------------------------------------------------------------------------------------
+# parent mode: start one rank per GPU
+
+def spawn_ranks(n, argv):
+    """Run this script under torch.distributed.run with n local ranks and relay rank 0's line.
+    Nothing in this process has touched a GPU (torch is not even imported yet)."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.lstrip().startswith('{'):
+            sys.stdout.write(line)
+        else:
+            sys.stderr.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+# ---------------------------------------------------------------------------------------------
+# models and the CPU baseline
 
 def make_net(kind):
     """The product model with seeded random weights (no checkpoints ship): torch's default initialisation of
     the modules under the reference's seed (core/train.py:56), BatchNorm statistics perturbed away from the
     identity.  Nothing from oracle/ is involved in the measured path."""
+    import torch
     import voice_activity_detection_amd as pkg
     torch.manual_seed(1337)
     if kind == 'gru_h90':                              # no class in the reference: GRU(24, 90) + the same heads
@@ -88,10 +136,20 @@ def make_models(kind):
     return net, ref.eval()
 
 
-def cpu_baseline(kind, budget_s=12.0):
-    """The CPU oracle (float64 numpy MFCC + torch CPU model, batch 2048) on a bounded sample: once with torch's
-    default thread count, once (shorter) with a single thread."""
+def cpu_baseline(kind, budget_s=14.0):
+    """The CPU oracle (float64 numpy/scipy MFCC + torch CPU model, batch 2048) on a bounded sample of the same
+    workload, twice: single-threaded and with the box's CPU share as torch/BLAS threads.  The path is a chain of
+    small operations (166-frame FFT batches, 30 GRU steps of (2048,30)x(30,90) products), so extra threads mostly
+    add synchronisation; `value` is the faster leg and both are reported."""
+    import torch
     from oracle import pipeline_ref, synth_ref
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                                # BLAS keeps its own default then
+        from contextlib import nullcontext
+
+        def threadpool_limits(limits=None):
+            return nullcontext()
     _, ref = make_models(kind)
     minute = synth_ref.synth_frames(0, 2000, seed=1337)            # 1 min = 2000 frames
     pipeline_ref.vad_stream(ref, minute[:400])                     # warm-up
@@ -106,17 +164,69 @@ def cpu_baseline(kind, budget_s=12.0):
             if dt >= budget or reps >= 200:
                 return reps, dt
 
-    threads = torch.get_num_threads()
-    reps, dt = leg(budget_s)
-    torch.set_num_threads(1)
-    reps1, dt1 = leg(budget_s / 3)
-    torch.set_num_threads(threads)
-    return {'value': reps * 2000 / FRAMES_PER_HOUR / dt, 'unit': 'audio-hours/s', 'cores': threads, 'kind': 'port',
-            'single_thread_value': reps1 * 2000 / FRAMES_PER_HOUR / dt1,
+    before = torch.get_num_threads()
+    share = max(1, min(int(os.environ.get('OMP_NUM_THREADS', '0') or 0) or before, os.cpu_count() or 1))
+    legs = {}
+    for threads in sorted({1, share}):
+        torch.set_num_threads(threads)
+        with threadpool_limits(limits=threads):
+            reps, dt = leg(budget_s / 2)
+        legs[threads] = {'value': reps * 2000 / FRAMES_PER_HOUR / dt, 'reps': reps, 'seconds': dt}
+    torch.set_num_threads(before)
+    best = max(legs, key=lambda k: legs[k]['value'])
+    return {'value': legs[best]['value'], 'unit': 'audio-hours/s', 'cores': best, 'kind': 'port',
+            'by_threads': {str(k): v['value'] for k, v in legs.items()},
             'sample': '%d x 1 min synthetic audio (2000 frames, 1971 windows each), float64 numpy/scipy MFCC+delta '
-                      'in 166-frame slices + torch CPU %s, batch 2048; %.1f s of CPU work (+ %.1f s single-threaded), '
-                      'host has %d CPUs' % (reps, kind, dt, dt1, os.cpu_count())}
+                      'in 166-frame slices + torch CPU %s, batch 2048; %s; host has %d CPUs'
+                      % (legs[best]['reps'], kind,
+                         ', '.join('%d thread(s): %d reps in %.1f s' % (k, v['reps'], v['seconds'])
+                                   for k, v in legs.items()), os.cpu_count())}
 
+
+# ---------------------------------------------------------------------------------------------
+# HBM traffic and instruction counts measured by rocprofv3 --pmc passes (tools/pmc_summary.py --json)
+
+def csrc_hash():
+    """Identifies the kernel sources a counter profile belongs to."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, 'voice_activity_detection_amd', 'csrc')
+    for name in sorted(os.listdir(base)):
+        if name.endswith(('.hip', '.h')):
+            with open(os.path.join(base, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_profile():
+    """profiles/pmc_traffic.json if it was collected on this build of the kernels, else None: counters cannot
+    be read from inside this process, so a profile of other sources must not be reported as this run's."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+    except (OSError, ValueError):
+        return None
+    return prof if prof.get('csrc_hash') == csrc_hash() else None
+
+
+def pmc_per_unit(prof, kernel_name):
+    """Per-frame (per-window) figures of one kernel from the profile: HBM bytes and VALU wave-instructions."""
+    if not prof:
+        return None
+    for name, k in prof.get('kernels', {}).items():
+        if name == kernel_name and k.get('units'):
+            out = {'file': 'profiles/pmc_traffic.json', 'kernel': name}
+            if 'hbm_bytes' in k:
+                out['bytes_per_unit'] = k['hbm_bytes'] / k['units']
+            if 'SQ_INSTS_VALU' in k:
+                out['valu_insts_per_unit'] = k['SQ_INSTS_VALU'] / k['units']
+            if 'SQ_INSTS_MFMA' in k:
+                out['mfma_insts_per_unit'] = k['SQ_INSTS_MFMA'] / k['units']
+            return out
+    return None
+
+
+# ---------------------------------------------------------------------------------------------
 
 def main():
     ap = argparse.ArgumentParser()
@@ -124,20 +234,24 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--hours', type=float, default=100.0, help='audio hours per GPU per step')
-    ap.add_argument('--model', default='gru_large', choices=sorted(FLOP_PER_WINDOW))
+    ap.add_argument('--model', default='gru_large', choices=MODELS)
     ap.add_argument('--slice', type=int, default=166, help='frames per MFCC slice (reference test path: 166)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+    ap.add_argument('--no-configs', action='store_true', help='time the headline workload only')
     ap.add_argument('--matrix-mode', default='f32', choices=['f32', 'bf16x6', 'bf16x9'],
                     help='how the stride-1 GRU/LSTM kernels form float32 products (default: float32 MFMA)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np
+    import torch
+
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a GPU when rehearsing the
     # multi-rank path on a one-GPU box (timing is then meaningless, the control flow is not)
     backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
@@ -156,117 +270,158 @@ def main():
     from voice_activity_detection_amd.sharding import shard_plan
     pkg.init()
     pkg.set_matrix_mode(args.matrix_mode)
-    net = make_net(args.model)
+    prof = load_pmc_profile()
+    free_bytes = torch.cuda.mem_get_info()[0]
 
-    frames_per_gpu = int(round(args.hours * FRAMES_PER_HOUR))
-    # contiguous slice-aligned shard of one stream; the rank re-creates its own lead-in and halo,
-    # and scores exactly the windows that start inside its shard (no inter-rank traffic)
-    plan = shard_plan(frames_per_gpu * world, world, rank, args.slice)
-    n_frames, n_windows = plan['n_load'], plan['n_windows']
-    stream = pkg.synth_stream(plan['first'], n_frames, seed=1337)   # generated on the device, outside the timing
-    ws = pkg.StreamWorkspace(n_frames, stream.device)
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    def run_workload(model, hours, steps, warmup, buffers=None):
+        """Time `steps` passes of the path for `model` over this rank's shard of world x hours of audio.
+        Returns (record for rank 0, buffers for reuse by a workload of the same size)."""
+        frames_per_gpu = int(round(hours * FRAMES_PER_HOUR))
+        # contiguous slice-aligned shard of one stream; the rank re-creates its own lead-in and halo,
+        # and scores exactly the windows that start inside its shard (no inter-rank traffic)
+        plan = shard_plan(frames_per_gpu * world, world, rank, args.slice)
+        n_frames, n_windows = plan['n_load'], plan['n_windows']
+        if buffers is None or buffers[0] != (plan['first'], n_frames):
+            buffers = None                                           # release before allocating the next size
+            stream = pkg.synth_stream(plan['first'], n_frames, seed=1337)   # on the device, outside the timing
+            buffers = ((plan['first'], n_frames), stream, pkg.StreamWorkspace(n_frames, stream.device))
+        _, stream, ws = buffers
+        net = make_net(model)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
 
-    def step(events=None):
-        if events:
-            events[0].record()
-        pkg.mfcc_delta_stream(stream, n_frames, args.slice, out=ws.feat)
-        if events:
-            events[1].record()
-        net.score(ws.feat, window_stride=24, n_windows=n_windows, out=ws.p, decisions=ws.decision)
-        if events:
-            events[2].record()
+        def step(events=None):
+            if events:
+                events[0].record()
+            pkg.mfcc_delta_stream(stream, n_frames, args.slice, out=ws.feat)
+            if events:
+                events[1].record()
+            net.score(ws.feat, window_stride=24, n_windows=n_windows, out=ws.p, decisions=ws.decision)
+            if events:
+                events[2].record()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(ev[k])
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([plan['n_own']], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(tot)
-        total_frames = int(tot.item())
-    else:
-        total_frames = plan['n_own']
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(ev[k])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            tot = torch.tensor([plan['n_own']], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(tot)
+            total_frames = int(tot.item())
+        else:
+            total_frames = plan['n_own']
+        if rank != 0:
+            return None, buffers
 
-    if rank == 0:
+        # events are recorded on the stream the kernels are launched on (torch's current stream)
         fe_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         nn_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
         assert bool(torch.isfinite(ws.p).all())
         hours_per_step = total_frames / FRAMES_PER_HOUR
-        value = hours_per_step * args.steps / elapsed
-        flop = FLOP_PER_WINDOW[args.model] * n_windows
-        achieved = flop / (nn_ms * 1e-3) / 1e12
-        fe_tf = FRONTEND_FLOP_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e12
+        value = hours_per_step * steps / elapsed
+        flop_alg, flop_torch = FLOP_PER_WINDOW[model]
+        achieved = flop_alg * n_windows / (nn_ms * 1e-3) / 1e12
+        # fp32 MFMA (v_mfma_f32_32x32x2_f32) issues at the fp32 vector FMA rate and does not co-execute with
+        # vector instructions, so matrix and vector fp32 work share the one 157.3 TFLOP/s peak.
+        nn_pmc = pmc_per_unit(prof, MODEL_KERNEL[model])
+        model_roof = {
+            'bound': 'mfma', 'kernel': MODEL_KERNEL[model], 'model': model,
+            'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
+            'traffic': nn_pmc['bytes_per_unit'] * n_windows if nn_pmc and 'bytes_per_unit' in nn_pmc else None,
+            'traffic_from_profile': nn_pmc, 'ms_per_launch': nn_ms,
+            'algorithmic_bytes': (F * 4 + RESULT_BYTES_PER_WINDOW) * n_windows,
+            'flop_per_window': flop_alg, 'flop_per_window_pytorch': flop_torch, 'windows_per_launch': n_windows,
+            'note': 'achieved = algorithmic flops / time, with the per-row work (input projection / DenseNet stem) '
+                    'counted once per feature row as stride-1 windows need it; flop_per_window_pytorch counts it '
+                    'per (30,24) window as a batch framework does'}
         fe_gbs = FRONTEND_BYTES_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e9
-        # Both kernels are bound by the SIMDs' fp32 FMA lanes: v_mfma_f32_32x32x2_f32 runs at the fp32 vector
-        # rate and never co-executes with vector instructions (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/),
-        # so fp32 MFMA and fp32 VALU share one 157.3 TFLOP/s peak.
-        nn_traffic = TRAFFIC_BYTES_PER_FRAME.get(args.model)
-        model_roof = {'bound': 'mfma', 'kernel': 'model kernel (%s): rnn_stream_kernel / densenet_kernel' % args.model,
-                      'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                      'frac': achieved / PEAK_FP32_TFLOPS,
-                      'traffic': None if nn_traffic is None else nn_traffic * n_windows, 'ms_per_launch': nn_ms,
-                      'algorithmic_bytes': (24 * 4 + 9) * n_windows,
-                      'executed_flop_per_window': EXECUTED_FLOP_PER_WINDOW.get(args.model),
-                      'frac_executed': None if args.model not in EXECUTED_FLOP_PER_WINDOW else
-                      EXECUTED_FLOP_PER_WINDOW[args.model] * n_windows / (nn_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                      'flop_per_window': FLOP_PER_WINDOW[args.model], 'windows_per_launch': n_windows,
-                      'note': 'achieved = algorithmic (PyTorch-equivalent) flops / time; the stride-1 GRU/LSTM kernel '
-                              'projects each feature row once instead of once per window, so it executes ~0.69x of them'}
-        fe_roof = {'bound': 'mfma', 'kernel': 'mfcc_kernel (+ delta_kernel)', 'achieved': fe_tf, 'peak': PEAK_FP32_TFLOPS,
-                   'unit': 'TFLOP/s', 'frac': fe_tf / PEAK_FP32_TFLOPS,
-                   'traffic': TRAFFIC_BYTES_PER_FRAME['frontend'] * n_frames, 'ms_per_launch': fe_ms,
-                   'algorithmic_bytes': FRONTEND_BYTES_PER_FRAME * n_frames,
-                   'flop_per_frame': FRONTEND_FLOP_PER_FRAME, 'frames_per_launch': n_frames,
-                   'pipe': 'fp32 vector ALU (same FMA lanes as fp32 MFMA)',
-                   'hbm_GBs': fe_gbs, 'hbm_frac': fe_gbs / PEAK_HBM_GBS, 'bytes_per_frame': FRONTEND_BYTES_PER_FRAME}
-        out = {
-            'metric': 'audio-hours processed/sec (MFCC+GRU-30k VAD)' if args.model == 'gru_large'
-                      else 'audio-hours processed/sec (MFCC+%s VAD)' % args.model, 'value': value, 'unit': 'audio-hours/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        fe_tf = FRONTEND_FLOP_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e12
+        fe_pmc = pmc_per_unit(prof, 'mfcc_kernel')
+        fe_roof = {
+            'bound': 'hbm', 'kernel': 'mfcc_kernel', 'achieved': fe_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+            'frac': fe_gbs / PEAK_HBM_GBS,
+            'traffic': fe_pmc['bytes_per_unit'] * n_frames if fe_pmc and 'bytes_per_unit' in fe_pmc else None,
+            'traffic_from_profile': fe_pmc, 'ms_per_launch': fe_ms,
+            'algorithmic_bytes': FRONTEND_BYTES_PER_FRAME * n_frames, 'bytes_per_frame': FRONTEND_BYTES_PER_FRAME,
+            'frames_per_launch': n_frames, 'flop_per_frame': FRONTEND_FLOP_PER_FRAME, 'fp32_TFLOPs': fe_tf,
+            'fp32_frac': fe_tf / PEAK_FP32_TFLOPS,
+            'note': 'the kernel is not HBM-bound (61 flop per byte); its FFT is add-dominated (one flop per '
+                    'instruction slot), so the FMA peak is out of reach by construction and the second yardstick '
+                    'is vector-instruction issue: valu_issue'}
+        if fe_pmc and 'valu_insts_per_unit' in fe_pmc:
+            # the time the chip needs just to ISSUE the kernel's vector instructions at 2.4 GHz
+            issue_ms = fe_pmc['valu_insts_per_unit'] * n_frames * VALU_ISSUE_CYCLES / (SIMDS * 2.4e9) * 1e3
+            fe_roof['valu_issue'] = {'valu_wave_insts_per_frame': fe_pmc['valu_insts_per_unit'],
+                                     'cycles_per_inst': VALU_ISSUE_CYCLES, 'bound_ms': issue_ms,
+                                     'frac': issue_ms / fe_ms}
+        rec = {
+            'value': value, 'unit': 'audio-hours/s', 'steps': steps, 'warmup': warmup,
+            'ms_per_step': elapsed / steps * 1e3,
             'config': {'workload': '%s, %.0f h synthetic 16 kHz int16 audio per GPU, 12 MFCC + 12 delta, '
-                                   '%d-frame slices, stride-1 900 ms windows' % (args.model, args.hours, args.slice),
+                                   '%d-frame slices, stride-1 900 ms windows' % (model, hours, args.slice),
                        'frames_per_gpu': n_frames, 'windows_per_gpu': n_windows, 'parallelism': 'shards x%d' % world},
             'x_realtime_per_gpu': value * 3600.0 / world,
             'roofline': model_roof if nn_ms >= fe_ms else fe_roof,          # the longer of the two kernels
             'kernels': {'model': model_roof, 'frontend': fe_roof},
         }
-        if world == 1 and args.matrix_mode == 'f32' and args.model in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
-            # Not part of `value`: the same step with the recurrent and head products on the bf16 matrix pipe
-            # (float32 operands split exactly into three bf16; vad_set_matrix_mode), and how far its posteriors
-            # are from the float32-MFMA ones over every window of the workload.
-            p_f32 = ws.p.clone()
-            alt = {}
-            for mm in ('bf16x9', 'bf16x6'):
-                pkg.set_matrix_mode(mm)
-                step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    step()
-                torch.cuda.synchronize()
-                dt = (time.perf_counter() - t1) / 3
-                alt[mm] = {'value': hours_per_step / dt, 'unit': 'audio-hours/s', 'ms_per_step': dt * 1e3,
-                           'max_abs_posterior_diff_vs_f32': float((ws.p - p_f32).abs().max())}
-            pkg.set_matrix_mode('f32')
-            out['alt_matrix_modes'] = alt
-            del p_f32
+        return rec, buffers
+
+    head, buffers = run_workload(args.model, args.hours, args.steps, args.warmup)
+    out = None
+    if rank == 0:
+        out = {'metric': 'audio-hours processed/sec (MFCC+GRU-30k VAD)' if args.model == 'gru_large'
+                         else 'audio-hours processed/sec (MFCC+%s VAD)' % args.model,
+               'value': head['value'], 'unit': head['unit'], 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': head['ms_per_step'], 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': head['config'], 'x_realtime_per_gpu': head['x_realtime_per_gpu'],
+               'roofline': head['roofline'], 'kernels': head['kernels'], 'matrix_mode': args.matrix_mode}
+
+    if not args.no_configs and args.model == 'gru_large' and args.matrix_mode == 'f32':
+        # The other configurations of the measurement plan, 3 steps each on the buffers of the headline run:
+        # LSTM-small, DenseNet small and large, and the enlarged GRU (hidden 90).  With 8 ranks the enlarged
+        # GRU runs at its named size, 10 000 h over the node = 1 250 h (144 GB of int16) per GPU.
+        extra = {}
+        for model in ('lstm_small', 'densenet', 'densenet_large', 'gru_h90'):
+            rec, buffers = run_workload(model, args.hours, 3, 1, buffers)
+            extra[model] = rec
+        if world == 8 and free_bytes > 200e9:
+            buffers = None
+            rec, buffers = run_workload('gru_h90', 1250.0, 2, 1)
+            extra['gru_h90_10000h'] = rec
+        if rank == 0:
+            out['configs'] = extra
+
+    if rank == 0 and world == 1 and args.matrix_mode == 'f32' and \
+            args.model in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
+        # Not part of `value`: the same step with the recurrent and head products on the bf16 matrix pipe
+        # (float32 operands split exactly into three bf16; vad_set_matrix_mode), and how far its posteriors
+        # are from the float32-MFMA ones over every window of the workload.
+        rec, buffers = run_workload(args.model, args.hours, 1, 1, buffers)
+        _, stream, ws = buffers
+        p_f32 = ws.p.clone()
+        alt = {}
+        for mm in ('bf16x9', 'bf16x6'):
+            pkg.set_matrix_mode(mm)
+            rec, buffers = run_workload(args.model, args.hours, 3, 1, buffers)
+            alt[mm] = {'value': rec['value'], 'unit': 'audio-hours/s', 'ms_per_step': rec['ms_per_step'],
+                       'max_abs_posterior_diff_vs_f32': float((ws.p - p_f32).abs().max())}
+        pkg.set_matrix_mode('f32')
+        out['alt_matrix_modes'] = alt
+        del p_f32
+    if rank == 0:
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(args.model)
         print(json.dumps(out), flush=True)

@@ -216,8 +216,11 @@ int vad_overlay_i16(const int16_t* noise_dev, int64_t n_noise, const int16_t* sp
  * matrix of every threshold at once.  Replaces the per-candidate
  * `apply_threshold` (y >= t) + `confusion_matrix` of the FAR-at-fixed-FRR search
  * fix_frr (core/train.py:486-528), which rescans all scores for each t *= 1.1 step.
- * The comparison is (double)score >= t_k, as numpy.float32 against a Python float
- * evaluates in the reference; NaN scores are below every threshold.
+ * The comparison is exact: (double)score >= t_k; NaN scores are below every threshold.
+ * The reference's `y >= t` compares a numpy.float32 with a Python float, which numpy >= 2
+ * evaluates in float32 (t rounded to float32; numpy 1.x used float64): a caller that wants
+ * that rule passes thresholds already rounded to float32, as the host side's fix_frr does.
+ * The per-window decision of the forward calls (p1 >= threshold, float32) is the same rule.
  *   score_dev       float32, element i at score_dev[i * score_stride] (stride 2 reads
  *                   column 1 of an (n,2) posterior array in place)
  *   label_dev       uint8, non-zero = speech

@@ -10,9 +10,12 @@ from sklearn.metrics import confusion_matrix
 
 
 def apply_threshold(y_score, t=0.5):
-    """core/train.py:486-487; the scores are numpy.float32 scalars compared with a Python float.  The
-    comparison is made in float64 here whatever the installed numpy's scalar promotion rules."""
-    return [1 if np.float64(y) >= t else 0 for y in y_score]
+    """core/train.py:486-487; the scores are numpy.float32 scalars compared with a Python float.  The result
+    depends on the numpy the reference runs on (requirements.txt does not pin it): numpy >= 2 converts the
+    Python float to the scalar's type and compares in float32, numpy 1.x compared in float64.  The rule of
+    numpy >= 2 is the one restated here, explicitly, whatever numpy is installed."""
+    t32 = np.float32(t)
+    return [1 if np.float32(y) >= t32 else 0 for y in y_score]
 
 
 def fix_frr(y_true, y_score, frr_target, noise_level):

@@ -3,8 +3,11 @@
 
 TEST INFRASTRUCTURE ONLY (imported by tests/; the product path is vad_overlay_i16 on the GPU).
 
-PARITY UNPINNED: pydub and audioop are not importable here and the reference holds no vectors
-for this step.  Restated from their published behaviour:
+PINNED for its arithmetic: the standard library's audioop (the C module pydub calls for both steps)
+is importable here, and tests/test_oracle_overlay.py holds this restatement against audioop.mul +
+audioop.add (width 2) on the reference's three gains, the saturation edges and ragged lengths.
+pydub itself is not importable and the reference holds no vectors for this step, so pydub's control
+flow around the two calls is restated from its published behaviour:
   * pydub.AudioSegment.overlay: over the part of the base track (the noise) that the other
     segment (the speech) covers, the base is first passed through audioop.mul with factor
     db_to_float(gain) = 10 ** (gain / 20) when gain_during_overlay is truthy (None and 0

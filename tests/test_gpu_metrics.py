@@ -75,6 +75,23 @@ def test_fix_frr_matches_reference_loop(vad, lvl):
     assert got == (float(ref[0]), float(ref[1]))
 
 
+def test_fix_frr_score_equal_to_a_rounded_threshold(vad):
+    """float32(1e-4) < 1e-4 as doubles: a score of exactly float32(1e-4) reaches the first candidate threshold
+    under the float32 comparison of numpy >= 2 (and of the kernels' own decision), not under a double one."""
+    t0 = np.float32(1e-4)
+    assert float(t0) < 1e-4
+    y = np.array([1] * 50 + [0] * 50)
+    s = np.r_[t0, np.full(49, 0.9), np.full(25, 1.05e-4), np.full(25, 0.9)].astype(np.float32)
+    got = vad.fix_frr(y, s, 1, 'None')
+    ref = metrics_ref.fix_frr(list(y), list(s), 1, 'None')
+    assert got == (float(ref[0]), float(ref[1]))
+    # at t = 1e-4 the tied speech score is still accepted (FRR 0, FAR 100 %); the search stops at the next
+    # candidate, 1.1e-4, with FRR 2 % and FAR 50 %.  A double comparison would have stopped at 1e-4: (100, 2).
+    assert got == (50.0, 2.0)
+    tp, fp, _, _ = vad.threshold_sweep(y, s, [float(t0), 1e-4])
+    assert tp[0] == 50 and tp[1] == 49                   # the sweep itself compares exactly, in double
+
+
 def test_fix_frr_target_not_reached(vad):
     y = np.array([1, 1, 0, 0])
     s = np.array([1.0, 1.0, 0.0, 0.0], np.float32)

@@ -82,3 +82,14 @@ def test_shard_ranges_tile_the_stream(world, total):
     if world > 1 and total >= SLICE * world:
         sizes = [n for _, n in ranges]
         assert max(sizes) - min(sizes) < 2 * SLICE
+
+
+def test_one_slice_streams_are_not_sharded():
+    """slice_len <= 0 means "the whole stream is one slice": a cut would restart the pre-emphasis and the
+    delta edges mid-stream, so more than one rank is refused and one rank owns everything."""
+    assert shard_range(1000, 1, 0, 0) == (0, 1000)
+    assert shard_plan(1000, 1, 0, -1)['n_windows'] == 971
+    with pytest.raises(ValueError):
+        shard_range(1000, 2, 1, 0)
+    with pytest.raises(ValueError):
+        shard_plan(1000, 4, 0, -1)

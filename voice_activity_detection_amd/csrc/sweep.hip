@@ -4,8 +4,9 @@
 // core/train.py:489-528: apply_threshold `y >= t` + confusion_matrix per candidate t, t *= 1.1)
 // recomputes from scratch for each of its ~100-200 candidates.
 //
-// The comparison is done in double precision (a float32 score against a float64 threshold), which
-// is how the reference's `y >= t` evaluates numpy.float32 scores against a Python float.
+// The comparison is exact, in double precision (a float32 score against a float64 threshold).  The
+// reference's `y >= t` (numpy.float32 against a Python float) is a float32 comparison under numpy >= 2:
+// callers that want that rule round their thresholds to float32 first.
 // Integer counting only: results are exact and independent of the launch geometry.
 
 #include "vad_internal.h"

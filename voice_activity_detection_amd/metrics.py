@@ -99,8 +99,14 @@ def frr_thresholds(noise_level):
 
 def fix_frr(y_true, y_score, frr_target, noise_level):
     """FAR (%) at the first threshold whose FRR (%) reaches ``frr_target``; the last candidate's
-    pair if none does.  Same result as fix_frr in core/train.py:489-528, from one pass over the scores."""
-    thr = frr_thresholds(noise_level)
+    pair if none does.  Same result as fix_frr in core/train.py:489-528, from one pass over the scores.
+
+    The reference compares numpy.float32 scores with a Python float threshold (``y >= t``).  Under
+    numpy >= 2 that comparison is made in float32, i.e. against the threshold rounded to float32 --
+    the same rule as the model kernels' ``p1 >= threshold`` decision -- so the candidates are rounded
+    to float32 before the sweep (whose own comparison is exact, in double).  numpy 1.x compared in
+    float64; the two rules differ only for a score equal to a rounded threshold."""
+    thr = [float(np.float32(t)) for t in frr_thresholds(noise_level)]
     tp, fp, pos, neg = threshold_sweep(y_true, y_score, thr)
     far = frr = 0
     for k in range(len(thr)):

@@ -20,7 +20,11 @@ def shard_range(total_frames, world, rank, slice_len=SLICE_MAX):
     if not 0 <= rank < world:
         raise ValueError('rank %d outside world of %d' % (rank, world))
     if slice_len <= 0:
-        slice_len = 1
+        # the whole stream is ONE slice (as mfcc_delta_stream treats it): cutting it anywhere would restart
+        # the pre-emphasis and the delta edges at the cut, so it cannot be sharded
+        if world > 1:
+            raise ValueError('a stream processed as one slice (slice_len <= 0) cannot be sharded over %d ranks' % world)
+        slice_len = max(total_frames, 1)
     n_slices = (total_frames + slice_len - 1) // slice_len
     base, rem = divmod(n_slices, world)
     s0 = rank * base + min(rank, rem)
