@@ -236,6 +236,21 @@ int vad_threshold_sweep_f32(const float* score_dev, int64_t score_stride, const 
                             unsigned long long* hist_dev, int64_t* ge_dev, int64_t* total_dev, void* stream);
 
 /*
+ * The same sweep for callers that cannot allocate device memory and so have no workspace to pass
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+ * in the reference.  The (T+1) x 2 histogram lives in an array built into the library, 2 * (VAD_MAX_THRESHOLDS
+ * + 1) 64-bit words = 32 784 bytes per GPU, held from the library's load until the process ends; the call
+ * makes no hipMalloc / hipFree and clears the array itself.  n_thresholds > VAD_MAX_THRESHOLDS is
+ * rejected with VAD_EINVAL.  All calls on one GPU share that array: calls that overlap on one GPU
+ * (different streams or host threads) race; calls on one stream, or on different GPUs, do not.
+ * vad_init() looks the array's device address up for the current device; a caller that captures graphs
+ * calls it beforehand, as for the other entry points.  Results equal vad_threshold_sweep_f32's.
+ */
+int vad_threshold_sweep_noalloc_f32(const float* score_dev, int64_t score_stride, const uint8_t* label_dev, int64_t n,
+                                    const double* thresholds_dev, int n_thresholds,
+                                    int64_t* ge_dev, int64_t* total_dev, void* stream);
+
+/*
  * Deterministic synthetic 16 kHz int16 audio, written on the device: sample n
  * of stream `seed` is a pure integer function of (seed, n), reproducible on
  * the host.  No counterpart in the reference (its audio comes from datasets

@@ -24,7 +24,7 @@ SYMBOLS = [
     'vad_net_blob_floats', 'vad_pack_net_weights',
     'vad_densenet_blob_floats', 'vad_densenet_tensor_count', 'vad_pack_densenet_weights',
     'vad_gru_forward_f32', 'vad_lstm_forward_f32', 'vad_densenet_forward_f32',
-    'vad_synth_audio_i16', 'vad_overlay_i16', 'vad_threshold_sweep_f32',
+    'vad_synth_audio_i16', 'vad_overlay_i16', 'vad_threshold_sweep_f32', 'vad_threshold_sweep_noalloc_f32',
     'vad_set_matrix_mode', 'vad_get_matrix_mode', 'vad_gru_forward_rows_f32', 'vad_lstm_forward_rows_f32', 'vad_densenet_forward_rows_f32',
 ]
 
@@ -103,6 +103,8 @@ def lib():
     L.vad_overlay_i16.argtypes = [c_void, c_i64, c_void, c_i64, ctypes.c_int, ctypes.c_double, c_void, c_void]
     L.vad_threshold_sweep_f32.restype = ctypes.c_int
     L.vad_threshold_sweep_f32.argtypes = [c_void, c_i64, c_void, c_i64, c_void, ctypes.c_int, c_void, c_void, c_void, c_void]
+    L.vad_threshold_sweep_noalloc_f32.restype = ctypes.c_int
+    L.vad_threshold_sweep_noalloc_f32.argtypes = [c_void, c_i64, c_void, c_i64, c_void, ctypes.c_int, c_void, c_void, c_void]
     L.vad_set_matrix_mode.restype = ctypes.c_int
     L.vad_set_matrix_mode.argtypes = [ctypes.c_int]
     L.vad_get_matrix_mode.restype = ctypes.c_int

@@ -70,7 +70,9 @@ extern "C" int vad_init(void) {
     if (rc != VAD_OK) return rc;
     rc = vad::ensure_rnn_attrs();
     if (rc != VAD_OK) return rc;
-    return vad::ensure_densenet_attrs();
+    rc = vad::ensure_densenet_attrs();
+    if (rc != VAD_OK) return rc;
+    return vad::ensure_sweep_scratch();
 }
 
 extern "C" int vad_synth_audio_i16(int16_t* out_dev, int64_t first_sample, int64_t n_samples, uint32_t seed,

@@ -9,6 +9,8 @@
 // callers that want that rule round their thresholds to float32 first.
 // Integer counting only: results are exact and independent of the launch geometry.
 
+#include <mutex>
+
 #include "vad_internal.h"
 
 namespace vad {
@@ -137,16 +139,15 @@ __global__ __launch_bounds__(256) void sweep_suffix_kernel(const unsigned long l
 }  // namespace
 }  // namespace vad
 
-extern "C" int vad_threshold_sweep_f32(const float* score_dev, int64_t score_stride, const uint8_t* label_dev,
-                                       int64_t n, const double* thresholds_dev, int n_thresholds,
-                                       unsigned long long* hist_dev, int64_t* ge_dev, int64_t* total_dev, void* stream) {
-    using namespace vad;
-    VAD_REQUIRE(n >= 0 && score_stride >= 1, "n must be >= 0 and score_stride >= 1");
-    VAD_REQUIRE(n_thresholds >= 1 && n_thresholds <= kMaxThresholds, "n_thresholds must be in 1..%d", kMaxThresholds);
-    VAD_REQUIRE(thresholds_dev && hist_dev && ge_dev && total_dev && (n == 0 || (score_dev && label_dev)),
-                "null pointer argument");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    VAD_HIP_CHECK(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * 2 * (n_thresholds + 1), st));
+namespace vad {
+namespace {
+
+// The shared launch sequence: clear the (T+1) x 2 histogram, count, suffix-sum.  `hist` is device memory of
+// at least 2 * (T + 1) 64-bit words: the caller's workspace or this library's own scratch array.
+int sweep_launch(const float* score_dev, int64_t score_stride, const uint8_t* label_dev, int64_t n,
+                 const double* thresholds_dev, int n_thresholds, unsigned long long* hist, int64_t* ge_dev,
+                 int64_t* total_dev, hipStream_t st) {
+    VAD_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(unsigned long long) * 2 * (n_thresholds + 1), st));
     if (n > 0) {
         long blocks = (n + kSweepThreads * 64 - 1) / (kSweepThreads * 64);
         if (blocks > 1024) blocks = 1024;
@@ -157,14 +158,82 @@ extern "C" int vad_threshold_sweep_f32(const float* score_dev, int64_t score_str
                          (reinterpret_cast<uintptr_t>(label_dev) & 3) == 0;
         if (vec)
             hipLaunchKernelGGL(sweep_hist_kernel<true>, dim3((unsigned)blocks), dim3(kSweepThreads), 0, st, score_dev,
-                               (long)score_stride, label_dev, (long)n, thresholds_dev, n_thresholds, hist_dev);
+                               (long)score_stride, label_dev, (long)n, thresholds_dev, n_thresholds, hist);
         else
             hipLaunchKernelGGL(sweep_hist_kernel<false>, dim3((unsigned)blocks), dim3(kSweepThreads), 0, st, score_dev,
-                               (long)score_stride, label_dev, (long)n, thresholds_dev, n_thresholds, hist_dev);
+                               (long)score_stride, label_dev, (long)n, thresholds_dev, n_thresholds, hist);
         VAD_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(sweep_suffix_kernel, dim3(1), dim3(256), 0, st, hist_dev, n_thresholds,
+    hipLaunchKernelGGL(sweep_suffix_kernel, dim3(1), dim3(256), 0, st, hist, n_thresholds,
                        reinterpret_cast<long long*>(ge_dev), reinterpret_cast<long long*>(total_dev));
     VAD_HIP_CHECK(hipGetLastError());
     return VAD_OK;
+}
+
+int check_sweep_args(const float* score_dev, int64_t score_stride, const uint8_t* label_dev, int64_t n,
+                     const double* thresholds_dev, int n_thresholds, const int64_t* ge_dev, const int64_t* total_dev) {
+    VAD_REQUIRE(n >= 0 && score_stride >= 1, "n must be >= 0 and score_stride >= 1");
+    VAD_REQUIRE(n_thresholds >= 1 && n_thresholds <= kMaxThresholds, "n_thresholds must be in 1..%d, got %d",
+                kMaxThresholds, n_thresholds);
+    VAD_REQUIRE(thresholds_dev && ge_dev && total_dev && (n == 0 || (score_dev && label_dev)), "null pointer argument");
+    return VAD_OK;
+}
+
+}  // namespace
+}  // namespace vad
+
+// The histogram of the entry point that takes no workspace: one array per GPU, inside the code object, so no
+// call ever allocates it.  In host code `scratch` is only a handle for hipGetSymbolAddress; kernels and memsets
+// get the device address looked up below.
+static __device__ __align__(256) unsigned long long scratch[2 * (VAD_MAX_THRESHOLDS + 1)];
+
+namespace vad {
+namespace {
+constexpr int kMaxSweepDevices = 64;
+std::mutex g_scratch_mu;
+unsigned long long* g_scratch_ptr[kMaxSweepDevices] = {nullptr};      // per device: that GPU's copy of `scratch`
+}  // namespace
+
+// Device address of `scratch` on the current device, looked up once per device.
+int sweep_scratch(unsigned long long** out) {
+    int dev = 0;
+    VAD_HIP_CHECK(hipGetDevice(&dev));
+    VAD_REQUIRE(dev >= 0 && dev < kMaxSweepDevices, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        VAD_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        VAD_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address for the sweep scratch");
+        g_scratch_ptr[dev] = static_cast<unsigned long long*>(p);
+    }
+    if (out) *out = g_scratch_ptr[dev];
+    return VAD_OK;
+}
+
+int ensure_sweep_scratch() { return sweep_scratch(nullptr); }
+
+}  // namespace vad
+
+extern "C" int vad_threshold_sweep_f32(const float* score_dev, int64_t score_stride, const uint8_t* label_dev,
+                                       int64_t n, const double* thresholds_dev, int n_thresholds,
+                                       unsigned long long* hist_dev, int64_t* ge_dev, int64_t* total_dev, void* stream) {
+    using namespace vad;
+    const int rc = check_sweep_args(score_dev, score_stride, label_dev, n, thresholds_dev, n_thresholds, ge_dev, total_dev);
+    if (rc != VAD_OK) return rc;
+    VAD_REQUIRE(hist_dev, "null pointer argument");
+    return sweep_launch(score_dev, score_stride, label_dev, n, thresholds_dev, n_thresholds, hist_dev, ge_dev, total_dev,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int vad_threshold_sweep_noalloc_f32(const float* score_dev, int64_t score_stride, const uint8_t* label_dev,
+                                               int64_t n, const double* thresholds_dev, int n_thresholds,
+                                               int64_t* ge_dev, int64_t* total_dev, void* stream) {
+    using namespace vad;
+    const int rc = check_sweep_args(score_dev, score_stride, label_dev, n, thresholds_dev, n_thresholds, ge_dev, total_dev);
+    if (rc != VAD_OK) return rc;
+    unsigned long long* hist = nullptr;
+    const int rs = sweep_scratch(&hist);                   // a table lookup after the device's first call / vad_init
+    if (rs != VAD_OK) return rs;
+    return sweep_launch(score_dev, score_stride, label_dev, n, thresholds_dev, n_thresholds, hist, ge_dev, total_dev,
+                        reinterpret_cast<hipStream_t>(stream));
 }

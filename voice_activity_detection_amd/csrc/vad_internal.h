@@ -41,6 +41,9 @@ int launch_delta(const float* mfcc_dev, long mfcc_ld, long n_frames, long frames
 int ensure_rnn_attrs();
 int ensure_densenet_attrs();   // the same for the stride-1 DenseNet kernels; defined in densenet.hip
 
+// Looks up, once per device, the address of the built-in histogram of vad_threshold_sweep_noalloc_f32; sweep.hip.
+int ensure_sweep_scratch();
+
 // Where the windows of a model launch start.  rows == nullptr: window w starts at x + w * stride floats
 // (stride 24 = stride-1 windows of a packed feature matrix, 720 = dense (B,30,24) batch).  Otherwise window w
 // starts at feature row rows[w] of a packed (n_rows, 24) matrix (sampled windows); a row index outside
