@@ -95,6 +95,25 @@ int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, int64_t fram
                        void* stream);
 
 /*
+ * The same front end over ONE contiguous stream cut into slices of different lengths: the loop of
+ * process_training_data (core/process_data.py:123-158), which calls add_noise once per randomly sized
+ * slice (33..166 frames, :88, :99) with the previous 3 frames of the same output stream as alignment rows
+ * (:145), becomes one launch per noise level.
+ *
+ * frames_dev         int16, (n_frames + 3) * 480 samples: 3 alignment rows (zeros for the start of a
+ *                    recording, :143), then the n_frames data rows; slice s covers rows
+ *                    slice_starts[s] .. slice_starts[s+1] - 1 and its alignment rows are the 3 rows before.
+ * slice_starts_dev   n_slices + 1 ascending int64 on the device, [0] = 0, [n_slices] = n_frames;
+ *                    empty slices are allowed.
+ * max_slice_frames   an upper bound of the slice lengths (sizes the launch: one wave per slice up to 256
+ *                    frames).  A longer slice is still computed in full, only less evenly spread.
+ * Outputs and per-slice semantics as vad_mfcc_delta_f32: output row g = frame g of the stream.
+ */
+int vad_mfcc_delta_slices_f32(const int16_t* frames_dev, const int64_t* slice_starts_dev, int64_t n_slices,
+                              int64_t n_frames, int64_t max_slice_frames,
+                              float* mfcc_dev, int64_t mfcc_ld, float* delta_dev, int64_t delta_ld, void* stream);
+
+/*
  * Weight packing (host side, no GPU work).  State-dict tensors of the
  * reference module -> one float blob in the layout the kernels read
  * (MFMA A-operand order, BatchNorm folded).  The caller copies the blob to

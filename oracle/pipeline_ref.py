@@ -94,3 +94,57 @@ def vad_stream(net, frames, slice_len=SLICE_MAX, threshold=None, batch_size=BATC
     x = windows(feat)
     p = score_windows(net, x, batch_size)
     return feat, p, decide(p, threshold)
+
+
+def process_training_data(speech_frames, speech_labels, noise_frames, seed=1337):
+    """The loop of process_training_data (core/process_data.py:76-158) on in-memory arrays, one add_noise call
+    (overlay_ref.overlay + mfcc_ref.process_test_frames) per slice and noise level, with numpy's legacy global
+    generator seeded as at :76 and drawn from in the reference's order.  As in the reference (:139-153) the
+    variable holding the slice's frames is overwritten by add_noise's result, so the levels after the first mix
+    the noise into the previous level's output.  Returns the dict of arrays the HDF5 datasets would hold."""
+    from . import overlay_ref
+    SLICE_MIN, WINDOW = 33, 4                              # core/process_data.py:52, 49
+    levels = {'None': None, '-15': -15, '-3': -3}          # core/common.py:25
+    speech = np.asarray(speech_frames, np.int16).reshape(-1, 480)
+    noise_set = np.asarray(noise_frames, np.int16).reshape(-1, 480)
+    rng = np.random.RandomState(seed)
+    pos, l, slices = 0, len(speech), []
+    while pos + SLICE_MIN < l:                             # :87-90
+        s = (pos, pos + rng.randint(SLICE_MIN, SLICE_MAX + 1))
+        slices.append(s)
+        pos = s[1]
+    slices[-1] = (slices[-1][0], l)                        # :93
+    pos = 0
+    while pos + SLICE_MIN < l:                             # :98-102
+        length = rng.randint(SLICE_MIN, SLICE_MAX + 1)
+        slices.append((length, length))
+        pos += length
+    total = l + pos + WINDOW                               # :105
+    rng.shuffle(slices)                                    # :108
+    data = {'labels': np.zeros((total,), np.int8)}
+    for key in levels:
+        data['frames-' + key] = np.zeros((total, 480), np.int16)
+        data['mfcc-' + key] = np.zeros((total, 12), np.float32)
+        data['delta-' + key] = np.zeros((total, 12), np.float32)
+    pos = 0
+    for s in slices:                                       # :123-158
+        if s[0] == s[1]:
+            frames = np.zeros((s[0], 480))
+            labels = np.zeros(s[0])
+        else:
+            frames = speech[s[0]: s[1]]
+            labels = np.asarray(speech_labels)[s[0]: s[1]]
+        i = rng.randint(0, len(noise_set) - len(labels))
+        noise = noise_set[i: i + len(labels)]
+        for key in levels:
+            align = np.zeros((WINDOW - 1, 480)) if pos == 0 else data['frames-' + key][pos - WINDOW + 1: pos]
+            mixed = overlay_ref.overlay(np.int16(noise), np.int16(frames), levels[key]).reshape(-1, 480)   # add_noise :283-297
+            frames, mfcc, delta = mfcc_ref.process_test_frames(mixed, np.int16(align))                      # add_noise :299-309
+            data['frames-' + key][pos: pos + len(labels)] = frames
+            data['mfcc-' + key][pos: pos + len(labels)] = mfcc
+            data['delta-' + key][pos: pos + len(labels)] = delta
+        data['labels'][pos: pos + len(labels)] = labels
+        pos += len(labels)
+    data['count'] = pos
+    data['slices'] = slices
+    return data

@@ -237,3 +237,86 @@ def test_process_test_data_matches_the_slice_loop(vad):
     assert not out['mfcc'][pos:].any() and not out['frames'][pos:].any()
     assert out['mfcc'].dtype == np.float32 and out['labels'].dtype == np.int8
     assert vad.process_test_data(fr[:100], labels[:100])['count'] == 0
+
+
+@pytest.mark.parametrize('lengths', [[33, 166, 1, 40, 166, 7], [166] * 3 + [5], [300, 2, 2, 700], [1] * 9, [0, 50, 0, 0, 34]])
+def test_ragged_slices_match_per_slice_calls(vad, lengths):
+    """vad_mfcc_delta_slices_f32: one launch over slices of different lengths (the training-data loop's
+    33..166-frame cuts, also degenerate, empty and longer-than-a-block ones) against one oracle call per slice."""
+    starts = np.concatenate(([0], np.cumsum(lengths)))
+    n = int(starts[-1])
+    stream = vad.synth_stream(0, n, seed=21)
+    feat = vad.mfcc_delta_ragged(stream, starts).cpu().numpy()
+    host = stream.cpu().numpy().reshape(-1, 480)                         # 3 zero rows, then the frames
+    for lo, hi in zip(starts[:-1], starts[1:]):
+        if hi == lo:
+            continue
+        _, rm, rd = mfcc_ref.process_test_frames(host[lo + 3: hi + 3], host[lo: lo + 3])
+        assert_feat_close(feat[lo:hi, :12], rm, 'mfcc slice at %d' % lo)
+        assert_feat_close(feat[lo:hi, 12:], rd, 'delta slice at %d' % lo)
+    # the same slices through the uniform entry point, slice by slice: bit-identical
+    for lo, hi in zip(starts[:-1], starts[1:]):
+        if hi > lo:
+            mf, de = vad.mfcc_delta_slices(torch.from_numpy(host[lo: hi + 3][None]).cuda())
+            assert np.array_equal(mf[0].cpu().numpy(), feat[lo:hi, :12])
+            assert np.array_equal(de[0].cpu().numpy(), feat[lo:hi, 12:])
+
+
+def test_ragged_slices_understated_maximum_and_errors(vad):
+    """A slice longer than the stated max_slice_frames is still computed in full (its blocks wrap around)."""
+    import ctypes
+    from voice_activity_detection_amd import _lib
+    lengths = [40, 900, 35]
+    starts = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+    n = int(starts[-1])
+    stream = vad.synth_stream(0, n, seed=23)
+    want = vad.mfcc_delta_ragged(stream, starts)
+    got = torch.full((n, 24), float('nan'), device='cuda')
+    sd = torch.from_numpy(starts).cuda()
+    L = vad.lib()
+    for stated in (40, 300):
+        got.fill_(float('nan'))
+        _lib.check(L.vad_mfcc_delta_slices_f32(ctypes.c_void_p(stream.data_ptr()), ctypes.c_void_p(sd.data_ptr()), 3, n,
+                                               stated, ctypes.c_void_p(got.data_ptr()), 24,
+                                               ctypes.c_void_p(got.data_ptr() + 48), 24, _lib.current_stream()))
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        vad.mfcc_delta_ragged(stream, [0, 50, 40, n])
+    with pytest.raises(ValueError):
+        vad.mfcc_delta_ragged(stream, [0, n + 1])
+
+
+def test_long_single_slice_is_split_without_seams(vad):
+    """A one-slice stream longer than a block's run: the runs recompute two MFCC rows on either side of their
+    seams, so the result equals the oracle's single call, and a differently placed seam changes no bit."""
+    n = 1500
+    stream = vad.synth_stream(0, n, seed=1337)
+    feat = vad.mfcc_delta_stream(stream, n, 0)
+    host = stream.cpu().numpy().reshape(-1, 480)
+    _, rm, rd = mfcc_ref.process_test_frames(host[3:], host[:3])
+    assert_feat_close(feat[:, :12].cpu().numpy(), rm, 'mfcc')
+    assert_feat_close(feat[:, 12:].cpu().numpy(), rd, 'delta')
+    # interior rows do not depend on where the slice ends, hence not on where the last seams fall
+    shorter = vad.mfcc_delta_stream(stream, n - 100, 0)
+    assert torch.equal(shorter[: n - 102], feat[: n - 102])
+
+
+def test_process_training_data_matches_the_slice_loop(vad):
+    """One mix and one front-end launch per noise level against the reference's loop of add_noise calls
+    (restated on the oracle side, same random draws)."""
+    rng = np.random.default_rng(5)
+    speech = synth_ref.synth_frames(0, 700, seed=41)
+    labels = (np.arange(700) // 25 % 2).astype(np.int8)
+    noise = (synth_ref.synth_frames(5000, 900, seed=43) // 4).astype(np.int16)
+    got = vad.process_training_data(speech, labels, noise)
+    ref = pipeline_ref.process_training_data(speech, labels, noise)
+    assert got['count'] == ref['count'] and got['slices'] == ref['slices']
+    lens = sorted(s[0] if s[0] == s[1] else s[1] - s[0] for s in got['slices'])
+    assert lens[0] >= 33 and len(lens) > 8
+    np.testing.assert_array_equal(got['labels'], ref['labels'])
+    for key in ('None', '-15', '-3'):
+        np.testing.assert_array_equal(got['frames-' + key], ref['frames-' + key])
+        assert got['mfcc-' + key].shape == ref['mfcc-' + key].shape and got['mfcc-' + key].dtype == np.float32
+        assert_feat_close(got['mfcc-' + key], ref['mfcc-' + key], 'mfcc ' + key)
+        assert_feat_close(got['delta-' + key], ref['delta-' + key], 'delta ' + key)
+    assert not np.array_equal(got['frames-None'], got['frames--15'])

@@ -20,7 +20,7 @@ HEADERS = ['vad_internal.h', 'mfcc_device.h', 'rnn_device.h']
 
 # every symbol include/vad_amd.h declares
 SYMBOLS = [
-    'vad_abi_version', 'vad_last_error', 'vad_init', 'vad_mfcc_delta_f32',
+    'vad_abi_version', 'vad_last_error', 'vad_init', 'vad_mfcc_delta_f32', 'vad_mfcc_delta_slices_f32',
     'vad_net_blob_floats', 'vad_pack_net_weights',
     'vad_densenet_blob_floats', 'vad_densenet_tensor_count', 'vad_pack_densenet_weights',
     'vad_gru_forward_f32', 'vad_lstm_forward_f32', 'vad_densenet_forward_f32',
@@ -77,6 +77,8 @@ def lib():
     L.vad_init.restype = ctypes.c_int
     L.vad_mfcc_delta_f32.restype = ctypes.c_int
     L.vad_mfcc_delta_f32.argtypes = [c_void, c_i64, c_i64, c_i64, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_void]
+    L.vad_mfcc_delta_slices_f32.restype = ctypes.c_int
+    L.vad_mfcc_delta_slices_f32.argtypes = [c_void, c_void, c_i64, c_i64, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_void]
     L.vad_net_blob_floats.restype = ctypes.c_size_t
     L.vad_net_blob_floats.argtypes = [ctypes.c_int] * 3
     L.vad_pack_net_weights.restype = ctypes.c_int

@@ -21,8 +21,16 @@
 // the partner value is a register of another lane (ds_bpermute, no LDS image of Z); the power spectrum
 // is left in LDS for the mel stage.
 //
+// A wave owns a RUN of consecutive frames of one slice (a whole slice when it has at most 256 frames, as
+// the reference's 33..166-frame slices do) and walks it in rounds of 4 frames.  The MFCC rows of its last
+// three rounds stay in an LDS ring, from which the same wave forms the 5-tap delta
+// (python_speech_features.delta(feat, 2), core/process_data.py:277: the slice's own edge rows replicated) two
+// rows behind the MFCCs and writes both halves of a feature row together; a run that ends inside a long
+// slice computes two more MFCC rows on either side instead of exchanging them with its neighbour.  Waves
+// never wait for each other after the block's set-up.
+//
 // Occupancy is the design constraint: a wave stalls on its own LDS exchanges, so the kernel keeps three
-// waves per SIMD (<= 168 VGPRs, 24 KB of LDS per 2-wave block): the input is read straight from global
+// waves per SIMD (<= 168 VGPRs, 25 KB of LDS per 2-wave block): the input is read straight from global
 // memory (no block staging buffer), one of the three twiddle sets lives in a block-shared LDS table.
 //
 // Precision: FFT, power and mel sums in fp32; filter energies, log and DCT in
@@ -44,107 +52,140 @@ namespace {
 
 constexpr int kWavesPerBlock = 2;                            // small blocks schedule best (measured 2 < 3 < 4 << 6 waves)
 constexpr int kThreads = 64 * kWavesPerBlock;
-constexpr int kFramesPerBlock = kWavesPerBlock * kFramesPerWave;
 constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twiddle tables
-constexpr int kSmemBytes = kWavesPerBlock * kWaveLdsBytes + kTwBytes;
-constexpr int kWavesPerSimd = 3;                             // register budget 168; a block needs 24 KB of LDS
+constexpr int kRingRows = 3 * kFramesPerWave;                // MFCC rows a wave keeps for the delta stencil
+constexpr int kRingBytes = kRingRows * kNCep * 4;
+constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes;
+constexpr int kWavesPerSimd = 3;                             // register budget 168; a block needs 25 KB of LDS
+constexpr int kDeltaReach = 2;                               // delta(feat, 2) looks two rows to either side
+constexpr int kMaxRunFrames = 256;                           // frames one wave computes for one run, halo rows included
+constexpr int kLongRun = kMaxRunFrames - 2 * kDeltaReach;    // owned frames per run of a slice longer than kMaxRunFrames
 
-// Where frame g of the launch lives: slice s, frame j inside it.
-struct FramePos {
-    long s;
-    long j;
+// How the frames of a launch are cut into slices, and the slices into runs (one wave per run).
+struct SliceMap {
+    const int64_t* starts;      // ragged slices of one contiguous stream: n_slices + 1 first-frame indices; or nullptr:
+    long frames_per_slice;      //   uniform slices: every slice has this many frames, the last one what is left
+    long slice_stride;          //   uniform slices: samples from one slice's alignment rows to the next slice's
+    long n_frames;              // frames of the launch (= starts[n_slices])
+    long n_runs;                // n_slices * runs_per_slice
+    int runs_per_slice;         // waves per slice
+    int run_len;                // owned frames per run
 };
 
-// grid: one block per 8 consecutive frames of the launch (slices are not padded to blocks: a block may
-// straddle slices, each frame finds its own slice).  Wave w takes frames w, w+2, w+4, w+6 of the block, so
-// the waves walk neighbouring rows at the same time and the 4x re-read of every input row (hop 480,
-// window 1920, plus the pre-emphasis lag) is served by the caches.
+// Rows [j_first, j_first + n_emit) of a slice of n frames, from the wave's MFCC ring (row q at slot
+// (q - first) % kRingRows): 12 coefficients and their deltas, d[j] = (-2 f[j-2] - f[j-1] + f[j+1] + 2 f[j+2]) / 10
+// with the slice's own edge rows replicated.  One lane per output float: both halves of a packed 24-float row
+// go out together.
+__device__ __forceinline__ void emit_rows(const float* ring, int first, int n, int j_first, int n_emit, int lane,
+                                          float* __restrict__ mfcc, long mfcc_ld, float* __restrict__ delta, long delta_ld) {
+    for (int idx = lane; idx < n_emit * 2 * kNCep; idx += 64) {
+        const int r = idx / (2 * kNCep), c2 = idx - r * 2 * kNCep;
+        const int j = j_first + r;
+        const int c = c2 < kNCep ? c2 : c2 - kNCep;
+        auto at = [&](int q) {
+            q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
+            return ring[((q - first) % kRingRows) * kNCep + c];
+        };
+        if (c2 < kNCep) {
+            mfcc[(long)j * mfcc_ld + c] = at(j);
+        } else {
+            const float d = (2.0f * (at(j + 2) - at(j - 2)) + (at(j + 1) - at(j - 1))) / 10.0f;
+            delta[(long)j * delta_ld + c] = d;
+        }
+    }
+}
+
+// grid: one wave per run, two waves per block.  Frame j of a slice whose alignment rows start at `rows` reads
+// aligned rows j .. j+3 and their predecessors j-1 .. j+2 (row -1 does not exist: zero_first_pred), and is output
+// row g_lo + j.  Consecutive frames of a wave re-read three of their four rows: those hits are served by the
+// CU's vector L1 / the L2.
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int16_t* __restrict__ in,
-                                                                 const MfccTables* __restrict__ tab, long n_frames,
-                                                                 long frames_per_slice, long slice_stride,
-                                                                 float* __restrict__ out, long out_ld) {
+                                                                 const MfccTables* __restrict__ tab, SliceMap m,
+                                                                 float* __restrict__ mfcc, long mfcc_ld,
+                                                                 float* __restrict__ delta, long delta_ld) {
     __shared__ __align__(16) unsigned char smem[kSmemBytes];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    unsigned char* wbase = smem + wave * kWaveLdsBytes;
+    unsigned char* wbase = smem + wave * (kWaveLdsBytes + kRingBytes);
     float2* ex = reinterpret_cast<float2*>(wbase);                          // exchange 1 / 2, power spectrum
     float* en = reinterpret_cast<float*>(wbase + kExBytes);                  // [4 frames][32]
-
-    // block-uniform: slice and in-slice offset of the block's first frame
-    const long g0 = (long)blockIdx.x * kFramesPerBlock;
-    const long s0 = g0 / frames_per_slice;
-    const long r0 = g0 - s0 * frames_per_slice;
-    auto locate = [&](int jl) {                             // frame g0 + jl (wave-uniform)
-        FramePos p;
-        const long off = r0 + jl;
-        if (off < frames_per_slice) {
-            p.s = s0;
-            p.j = off;
-        } else if (frames_per_slice >= kFramesPerBlock) {   // at most one slice boundary inside a block
-            p.s = s0 + 1;
-            p.j = off - frames_per_slice;
-        } else {
-            const long ds = off / frames_per_slice;
-            p.s = s0 + ds;
-            p.j = off - ds * frames_per_slice;
-        }
-        return p;
-    };
-    // aligned row r of a slice = its frame r - 3; frame j reads rows j .. j+3 and their predecessors
-    // j-1 .. j+2 (row -1 does not exist: zero_first_pred).  Every slice holds its frames + 3 rows.
-    auto lane_ptr = [&](const FramePos& p) {
-        return reinterpret_cast<const int*>(in + p.s * slice_stride) + p.j * (kFrame / 2) + lane;
-    };
+    float* ring = reinterpret_cast<float*>(wbase + kWaveLdsBytes);           // [kRingRows][12]
+    const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
 
     LaneConst K;
     load_lane_const(K, tab, lane);
-    const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * kWaveLdsBytes);
-
-    RawFrame raw;
     {
         // tw1 is the first member of MfccTables
         const float4* src = reinterpret_cast<const float4*>(tab);
-        float4* dst = reinterpret_cast<float4*>(smem + kWavesPerBlock * kWaveLdsBytes);
+        float4* dst = reinterpret_cast<float4*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
         for (int i = threadIdx.x; i < kTwFloat2s / 2; i += kThreads) dst[i] = src[i];
         __syncthreads();
     }
 
-    int nfr = 0;                                            // frames this wave produced (wave-uniform)
-#pragma unroll 1
-    for (int it = 0; it < kFramesPerWave; ++it) {
-        const int jl = wave + it * kWavesPerBlock;
-        if (g0 + jl >= n_frames) break;
-        nfr = it + 1;
-        const FramePos p = locate(jl);
-        // (fetching the wave's next frame under the mel stage instead was measured slower: it costs
-        // 30 live registers and the third wave per SIMD already covers the load latency)
-        frame_load(raw, lane_ptr(p), p.j == 0, lane);
-        frame_energies(raw, tws, K, ex, en + it * 32, lane);
+    // wave-uniform from here on (the only block barrier is behind us): the wave's run
+    const long run = (long)blockIdx.x * kWavesPerBlock + wave;
+    if (run >= m.n_runs) return;
+    const long s = run / m.runs_per_slice;
+    const int part = (int)(run - s * m.runs_per_slice);
+    long g_lo;
+    int n;                                                   // frames of the slice (< 2^31, checked by the host)
+    const int16_t* rows;
+    if (m.starts) {
+        // the table is read through vector loads: tell the compiler the values are wave-uniform, or every loop
+        // variable derived from them occupies a vector register
+        const long lo = (long)m.starts[s], hi = (long)m.starts[s + 1];
+        g_lo = ((long)__builtin_amdgcn_readfirstlane((int)(lo >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(lo & 0xFFFFFFFFL));
+        n = __builtin_amdgcn_readfirstlane((int)(hi - lo));
+        rows = in + g_lo * kFrame;
+    } else {
+        g_lo = s * m.frames_per_slice;
+        n = (int)(m.n_frames - g_lo < m.frames_per_slice ? m.n_frames - g_lo : m.frames_per_slice);
+        rows = in + s * m.slice_stride;
     }
-    cepstra_tail(en, reinterpret_cast<double*>(wbase), &tab->dct[0][0], nfr, lane, out, out_ld, g0 + wave,
-                 kWavesPerBlock);
-}
+    const int* slice_dwords = reinterpret_cast<const int*>(rows);
+    mfcc += g_lo * mfcc_ld;                                  // row j of the slice is output row g_lo + j
+    delta += g_lo * delta_ld;
 
-// delta[g] = (-2 f[g-2] - f[g-1] + f[g+1] + 2 f[g+2]) / 10 with the slice's own edge rows
-// replicated (python_speech_features.delta(feat, 2), core/process_data.py:277).
-__global__ __launch_bounds__(256) void delta_kernel(const float* __restrict__ mfcc, long mfcc_ld, long n_frames,
-                                                    long frames_per_slice, float* __restrict__ delta, long delta_ld,
-                                                    long g_first, long g_count) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= g_count * kNCep) return;
-    const long g = g_first + idx / kNCep;
-    const int c = (int)(idx % kNCep);
-    const long s = g / frames_per_slice;
-    const long lo = s * frames_per_slice;
-    long hi = lo + frames_per_slice - 1;
-    if (hi > n_frames - 1) hi = n_frames - 1;
-    auto at = [&](long r) {
-        r = r < lo ? lo : (r > hi ? hi : r);
-        return mfcc[r * mfcc_ld + c];
-    };
-    const float d = (2.0f * (at(g + 2) - at(g - 2)) + (at(g + 1) - at(g - 1))) / 10.0f;
-    delta[g * delta_ld + c] = d;
+    // a slice longer than runs_per_slice * run_len (ragged slices beyond the caller's stated maximum) wraps around
+#pragma unroll 1
+    for (long j0l = (long)part * m.run_len; j0l < n; j0l += (long)m.runs_per_slice * m.run_len) {
+        const int j0 = (int)j0l;
+        const int own_hi = n - j0 < m.run_len ? n : j0 + m.run_len;         // owned frames [j0, own_hi)
+        const int first = j0 > kDeltaReach ? j0 - kDeltaReach : 0;          // computed frames [first, last)
+        const int last = n - own_hi < kDeltaReach ? n : own_hi + kDeltaReach;
+        int emitted = j0;                                                   // rows [j0, emitted) are written
+#pragma unroll 1
+        for (int fbase = first; fbase < last; fbase += kFramesPerWave) {
+            int nfr = 0;                                                    // frames of this round
+#pragma unroll 1
+            for (int it = 0; it < kFramesPerWave; ++it) {
+                const int j = fbase + it;
+                if (j >= last) break;
+                nfr = it + 1;
+                // (fetching the wave's next frame under the mel stage instead was measured slower: it costs
+                // 30 live registers and the third wave per SIMD already covers the load latency)
+                RawFrame raw;
+                frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
+                frame_energies(raw, tws, K, ex, en + it * 32, lane);
+            }
+            // the table entries a lane reads in the tail do not change from round to round: hide that from the
+            // compiler, which would otherwise keep them in registers across the FFT
+            const MfccTables* tail_tab = tab;
+            asm volatile("" : "+s"(tail_tab));
+            cepstra_tail(en, reinterpret_cast<double*>(wbase), &tail_tab->dctb[0][0], nfr, lane, ring, (fbase - first) % kRingRows, 1,
+                         kRingRows);
+            // MFCC rows [first, avail) are in the ring; a row can be written once the rows its delta reads are:
+            // everything owned in the last round, otherwise up to two rows behind.
+            const int avail = last - fbase > kFramesPerWave ? fbase + kFramesPerWave : last;
+            const int upto = avail == last ? own_hi : (avail - kDeltaReach < own_hi ? avail - kDeltaReach : own_hi);
+            const int n_emit = upto > emitted ? upto - emitted : 0;
+            emit_rows(ring, first, n, emitted, n_emit, lane, mfcc, mfcc_ld, delta, delta_ld);
+            emitted += n_emit;
+            wave_lds_fence();                                               // ring reads before the next round's writes
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -214,6 +255,11 @@ void build_tables(MfccTables& t) {
             const double lift = 1.0 + 11.0 * sin(pi * (double)k / 22.0);
             t.dct[n][k - 1] = sqrt(2.0 / kNFilt) * lift * cos(pi * (double)k * (2.0 * n + 1.0) / (2.0 * kNFilt));
         }
+    for (int s = 0; s < kDctSteps; ++s)
+        for (int l = 0; l < 64; ++l) {
+            const int n = 4 * s + (l >> 4), k = l & 15;
+            t.dctb[s][l] = (n < kNFilt && k < kNCep) ? t.dct[n][k] : 0.0;
+        }
 }
 
 constexpr int kMaxDevices = 64;
@@ -248,20 +294,34 @@ int ensure_mfcc_tables() {
     return VAD_OK;
 }
 
-}  // namespace vad
+namespace {
 
-namespace vad {
-// delta rows [g_first, g_first + g_count) of a stream of n_frames frames cut into frames_per_slice slices
-int launch_delta(const float* mfcc_dev, long mfcc_ld, long n_frames, long frames_per_slice, float* delta_dev,
-                 long delta_ld, long g_first, long g_count, hipStream_t st) {
-    if (g_count <= 0) return VAD_OK;
-    const long dblocks = (g_count * kNCep + 255) / 256;
-    VAD_REQUIRE(dblocks <= 0x7FFFFFFFL, "too many frames for one launch");
-    hipLaunchKernelGGL(delta_kernel, dim3((unsigned)dblocks), dim3(256), 0, st, mfcc_dev, mfcc_ld, n_frames,
-                       frames_per_slice, delta_dev, delta_ld, g_first, g_count);
+// One launch of the front end over the slices described by `m` (runs_per_slice and run_len are set here).
+int launch_mfcc(const int16_t* frames_dev, SliceMap m, long n_slices, long max_slice_frames, float* mfcc_dev, long mfcc_ld,
+                float* delta_dev, long delta_ld, hipStream_t st) {
+    int rc = ensure_mfcc_tables();
+    if (rc != VAD_OK) return rc;
+    int dev = 0;
+    VAD_HIP_CHECK(hipGetDevice(&dev));
+    if (max_slice_frames <= kMaxRunFrames) {                      // a block per slice: no halo rows anywhere
+        m.run_len = (int)max_slice_frames;
+        m.runs_per_slice = 1;
+    } else {
+        m.run_len = kLongRun;
+        const long runs = (max_slice_frames + kLongRun - 1) / kLongRun;
+        VAD_REQUIRE(runs <= 0x7FFFFFFFL, "slice too long for one launch");
+        m.runs_per_slice = (int)runs;
+    }
+    m.n_runs = n_slices * m.runs_per_slice;
+    const long blocks = (m.n_runs + kWavesPerBlock - 1) / kWavesPerBlock;
+    VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many frames for one launch");
+    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, frames_dev, g_tables[dev], m, mfcc_dev,
+                       mfcc_ld, delta_dev, delta_ld);
     VAD_HIP_CHECK(hipGetLastError());
     return VAD_OK;
 }
+
+}  // namespace
 }  // namespace vad
 
 extern "C" int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, int64_t frames_per_slice,
@@ -276,16 +336,29 @@ extern "C" int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, i
     VAD_REQUIRE(slice_stride >= 0 && (slice_stride % 2) == 0, "slice_stride must be even and non-negative");
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(frames_dev) & 3) == 0, "frames_dev must be 4-byte aligned");
     VAD_REQUIRE(n_slices < (int64_t(1) << 40) && frames_per_slice < (int64_t(1) << 40), "size out of range");
-    int rc = ensure_mfcc_tables();
-    if (rc != VAD_OK) return rc;
-    int dev = 0;
-    VAD_HIP_CHECK(hipGetDevice(&dev));
-    const long n_frames = (long)((n_slices - 1) * frames_per_slice + last_slice_frames);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const long blocks = (n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
-    VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many frames for one launch");
-    hipLaunchKernelGGL(mfcc_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, st, frames_dev, g_tables[dev], n_frames,
-                       (long)frames_per_slice, (long)slice_stride, mfcc_dev, (long)mfcc_ld);
-    VAD_HIP_CHECK(hipGetLastError());
-    return launch_delta(mfcc_dev, mfcc_ld, n_frames, frames_per_slice, delta_dev, delta_ld, 0, n_frames, st);
+    SliceMap m{};
+    m.starts = nullptr;
+    m.frames_per_slice = (long)frames_per_slice;
+    m.slice_stride = (long)slice_stride;
+    m.n_frames = (long)((n_slices - 1) * frames_per_slice + last_slice_frames);
+    return launch_mfcc(frames_dev, m, (long)n_slices, (long)frames_per_slice, mfcc_dev, (long)mfcc_ld, delta_dev,
+                       (long)delta_ld, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int vad_mfcc_delta_slices_f32(const int16_t* frames_dev, const int64_t* slice_starts_dev, int64_t n_slices,
+                                         int64_t n_frames, int64_t max_slice_frames, float* mfcc_dev, int64_t mfcc_ld,
+                                         float* delta_dev, int64_t delta_ld, void* stream) {
+    using namespace vad;
+    VAD_REQUIRE(frames_dev && slice_starts_dev && mfcc_dev && delta_dev, "null pointer argument");
+    VAD_REQUIRE(n_slices >= 1 && n_frames >= 1, "n_slices and n_frames must be >= 1");
+    VAD_REQUIRE(max_slice_frames >= 1, "max_slice_frames must be >= 1");
+    VAD_REQUIRE(mfcc_ld >= kNCep && delta_ld >= kNCep, "leading dimensions must be >= 12");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(frames_dev) & 3) == 0, "frames_dev must be 4-byte aligned");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(slice_starts_dev) & 7) == 0, "slice_starts_dev must be 8-byte aligned");
+    VAD_REQUIRE(n_slices < (int64_t(1) << 31) && n_frames < (int64_t(1) << 40), "size out of range");
+    SliceMap m{};
+    m.starts = slice_starts_dev;
+    m.n_frames = (long)n_frames;
+    return launch_mfcc(frames_dev, m, (long)n_slices, (long)max_slice_frames, mfcc_dev, (long)mfcc_ld, delta_dev,
+                       (long)delta_ld, reinterpret_cast<hipStream_t>(stream));
 }

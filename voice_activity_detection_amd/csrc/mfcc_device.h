@@ -13,6 +13,7 @@ constexpr int kNFilt = 26;
 constexpr int kNCep = VAD_NUM_CEPS;           // 12
 constexpr int kFramesPerWave = 4;              // frames whose log/DCT tail a wave batches
 constexpr int kMaxRun = 20;                   // bins per lane in the mel stage
+constexpr int kDctSteps = 7;                  // k-steps of 4 covering the 26 filters in the DCT matrix product
 constexpr int kEx1Stride = 272;               // exchange 1: complex elements per k1 row (256 + 16: the two
                                               // k1 rows of a 32-lane half land on opposite bank halves)
 constexpr int kEx2Plane = 272;                // exchange 2: complex elements per k1 plane (16 rows of 17): the two
@@ -34,6 +35,8 @@ struct MfccTables {
     int fall_first[kNFilt];  //          + falling parts of lanes [fall_first, +fall_n)
     int fall_n[kNFilt];
     double dct[kNFilt][kNCep];   // sqrt(2/26) * lifter(k) * cos(pi k (2n+1) / 52), k = 1..12
+    double dctb[kDctSteps][64];  // the same matrix as B operands of v_mfma_f64_16x16x4_f64: step s, lane l holds
+                                 // dct[4 s + (l >> 4)][l & 15], zero outside 26 x 12
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -274,28 +277,83 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     wave_lds_fence();
 }
 
-// Tail for up to 4 frames of one wave at once: log of the 26 energies (fp64), lifted DCT-II (fp64).
-// Frame `it` goes to output row g0 + it * gstep.  `logv` may alias the exchange region; `dct` is the
-// 26 x 12 table in global memory.
-__device__ __forceinline__ void cepstra_tail(const float* en, double* logv, const double* __restrict__ dct_s, int nfr, int lane,
-                                             float* __restrict__ out, long out_ld, long g0, long gstep) {
+// A double-precision constant the compiler cannot see through: the tail below sits inside the kernel's frame
+// loops, and constants it could name would be hoisted out of them into vector registers that the FFT needs
+// (the hoisted copies were spilled to scratch memory and reloaded one dependent load after the other).
+template <unsigned HI, unsigned LO>
+__device__ __forceinline__ double opaque_f64() {
+    unsigned lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"(LO), "i"(HI));
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+// Natural logarithm of a positive, normal double (every positive float32 widens to one), absolute error
+// below 3e-14 over the float32 range: x = m 2^e with m in [sqrt(1/2), sqrt 2), s = (m - 1) / (m + 1),
+// log m = 2 s + 2 s^3 / 3 + ... + 2 s^15 / 15.
+__device__ __forceinline__ double log_pos(double x) {
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    int e = ((hi >> 20) & 0x7FF) - 1023;
+    double m = __hiloint2double((hi & 0x000FFFFF) | 0x3FF00000, lo);               // [1, 2)
+    const bool big = m > opaque_f64<0x3FF6A09Eu, 0x667F3BCDu>();                    // sqrt 2
+    m = big ? m * 0.5 : m;
+    e += big ? 1 : 0;
+    const double d = m + 1.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    const double t = (m - 1.0) * r;
+    const double z = t * t;
+    double p = opaque_f64<0x3FC11111u, 0x11111111u>();                             // 2/15
+    p = fma(p, z, opaque_f64<0x3FC3B13Bu, 0x13B13B14u>());                         // 2/13
+    p = fma(p, z, opaque_f64<0x3FC745D1u, 0x745D1746u>());                         // 2/11
+    p = fma(p, z, opaque_f64<0x3FCC71C7u, 0x1C71C71Cu>());                         // 2/9
+    p = fma(p, z, opaque_f64<0x3FD24924u, 0x92492492u>());                         // 2/7
+    p = fma(p, z, opaque_f64<0x3FD99999u, 0x9999999Au>());                         // 2/5
+    p = fma(p, z, opaque_f64<0x3FE55555u, 0x55555555u>());                         // 2/3
+    return fma((double)e, opaque_f64<0x3FE62E42u, 0xFEFA39EFu>(), fma(t * z, p, t + t));   // e ln 2 + log m
+}
+
+// Tail for up to 4 frames of one wave at once: log of the 26 energies (fp64), then the lifted DCT-II as one
+// small fp64 matrix product on the matrix cores, C[frame][k] = sum_n log E[frame][n] * dct[n][k] with
+// v_mfma_f64_16x16x4_f64 (M = 16 rows of which 4 are frames, N = 16 columns of which 12 are coefficients,
+// K = 26 in 7 steps of 4): lane l supplies A[l & 15][4 s + (l >> 4)] and B[4 s + (l >> 4)][l & 15] and ends up
+// with C[4 r + (l >> 4)][l & 15] in accumulator element r (layout measured by tools/probes/mfma_f64_layout.hip),
+// so element 0 of lane l is coefficient l & 15 of frame l >> 4.
+// The 12 coefficients of frame `it` go to rows[slot(it) * 12 ..), slot(it) = (slot0 + it * slot_step) % n_slots,
+// a ring of MFCC rows in LDS.  `logv` may alias the exchange region; `dctb` is MfccTables::dctb in global memory.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// A pointer known to point into global memory (plain global_load instead of the generic flat_load, which the
+// compiler falls back to once a pointer has passed through inline assembly).
+__device__ __forceinline__ const __attribute__((address_space(1))) double* global_f64(const double* p) {
+    return (const __attribute__((address_space(1))) double*)p;
+}
+
+__device__ __forceinline__ void cepstra_tail(const float* en, double* logv, const double* __restrict__ dctb, int nfr, int lane,
+                                             float* rows, int slot0, int slot_step, int n_slots) {
 #pragma unroll
     for (int r = 0; r < kFramesPerWave / 2; ++r) {
         const int it = 2 * r + (lane >> 5), f = lane & 31;
         if (f < kNFilt && it < nfr) {
             const float e = en[it * 32 + f];
-            logv[it * kNFilt + f] = log(e == 0.0f ? 2.220446049250313e-16 : (double)e);   // psf.fbank clamp
+            logv[it * kNFilt + f] = log_pos(e == 0.0f ? opaque_f64<0x3CB00000u, 0u>() : (double)e);   // psf.fbank clamp: eps = 2^-52
         }
     }
     wave_lds_fence();
-    if (lane < kFramesPerWave * kNCep) {
-        const int it = lane / kNCep, k = lane - it * kNCep;
-        if (it < nfr) {
-            double c = 0.0;
+    {
+        const int i = lane & 15, kk = lane >> 4;
+        double b[kDctSteps], a[kDctSteps];
 #pragma unroll
-            for (int n = 0; n < kNFilt; ++n) c = fma(logv[it * kNFilt + n], dct_s[n * kNCep + k], c);
-            out[(g0 + it * gstep) * out_ld + k] = (float)c;
+        for (int s = 0; s < kDctSteps; ++s) b[s] = global_f64(dctb)[s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < kDctSteps; ++s) {
+            const int n = 4 * s + kk;
+            a[s] = (i < nfr && n < kNFilt) ? logv[i * kNFilt + n] : 0.0;     // rows of frames that do not exist: 0
         }
+        f64x4 c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < kDctSteps; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+        if (i < kNCep && kk < nfr) rows[((slot0 + kk * slot_step) % n_slots) * kNCep + i] = (float)c[0];
     }
     wave_lds_fence();
 }

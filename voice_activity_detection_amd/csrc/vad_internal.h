@@ -33,10 +33,6 @@ void set_error(const char* fmt, ...);
 // Per-device constant tables of the MFCC front end; defined in mfcc.hip.
 int ensure_mfcc_tables();
 
-// delta rows [g_first, g_first + g_count) from the MFCC rows of a sliced stream; defined in mfcc.hip.
-int launch_delta(const float* mfcc_dev, long mfcc_ld, long n_frames, long frames_per_slice, float* delta_dev,
-                 long delta_ld, long g_first, long g_count, hipStream_t st);
-
 // One-time per-device opt-in of the model kernels that need more than 64 KB of LDS; defined in rnn.hip.
 int ensure_rnn_attrs();
 int ensure_densenet_attrs();   // the same for the stride-1 DenseNet kernels; defined in densenet.hip

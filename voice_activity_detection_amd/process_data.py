@@ -11,10 +11,14 @@ plus device-resident batch forms that the per-slice Python loop of
 
 * ``mfcc_delta_slices``  a batch of independently stored slices
 * ``mfcc_delta_stream``  one contiguous stream cut into fixed-length slices
+* ``mfcc_delta_ragged``  one contiguous stream cut into slices of different lengths
 * ``overlay_device``     the int16 noise/speech mix of add_noise on device tensors
 * ``process_test_data``  the whole per-slice loop of a recording as one call
+* ``process_training_data``  the slice x noise-level loop of the training set: one mix and one
+  front-end launch per noise level
 
-All arithmetic runs in ``vad_mfcc_delta_f32`` / ``vad_overlay_i16`` of libvad_amd.so.
+All arithmetic runs in ``vad_mfcc_delta_f32`` / ``vad_mfcc_delta_slices_f32`` / ``vad_overlay_i16`` of
+libvad_amd.so.
 """
 import ctypes
 
@@ -22,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .common import ALIGN_FRAMES, FRAME_SIZE, SLICE_MAX, SLICE_MIN
+from .common import ALIGN_FRAMES, FRAME_SIZE, MFCC_WINDOW_FRAME_SIZE, NOISE_LEVELS_DB, SEED, SLICE_MAX, SLICE_MIN
 
 
 def _device():
@@ -68,6 +72,41 @@ def mfcc_delta_stream(stream_dev, n_frames, slice_len=SLICE_MAX, out=None):
                                         slice_len * FRAME_SIZE,
                                         ctypes.c_void_p(out.data_ptr()), 24,
                                         ctypes.c_void_p(out.data_ptr() + 12 * 4), 24, _lib.current_stream()))
+    return out
+
+
+def mfcc_delta_ragged(stream_dev, slice_starts, out=None):
+    """Packed (n_frames, 24) float32 features of a contiguous device-resident stream cut into slices of
+    different lengths, one launch (``vad_mfcc_delta_slices_f32``).
+
+    ``stream_dev``    int16 CUDA tensor with (n_frames + 3) * 480 samples: 3 alignment rows, then the data rows.
+    ``slice_starts``  ascending first-frame indices of the slices, ``[0, ..., n_frames]`` (n_slices + 1 entries);
+                      an int64 CUDA tensor or any integer sequence.
+    Every slice is treated as its own call of the reference's feature function: its first alignment row is
+    not pre-emphasised and its deltas replicate its own edge rows.
+    """
+    L = _lib.lib()
+    if stream_dev.dtype != torch.int16 or not stream_dev.is_cuda or not stream_dev.is_contiguous():
+        raise ValueError('stream_dev must be a contiguous int16 CUDA tensor')
+    host = slice_starts.cpu().numpy() if torch.is_tensor(slice_starts) else np.asarray(slice_starts)
+    host = host.astype(np.int64).reshape(-1)
+    if host.size < 2 or host[0] != 0 or np.any(np.diff(host) < 0):
+        raise ValueError('slice_starts must be ascending, start at 0 and end at the frame count')
+    n_frames = int(host[-1])
+    if stream_dev.numel() < (n_frames + ALIGN_FRAMES) * FRAME_SIZE:
+        raise ValueError('stream_dev holds %d samples, need %d' %
+                         (stream_dev.numel(), (n_frames + ALIGN_FRAMES) * FRAME_SIZE))
+    if out is None:
+        out = torch.empty((n_frames, 24), dtype=torch.float32, device=stream_dev.device)
+    if n_frames == 0:
+        return out
+    starts = torch.from_numpy(host).to(stream_dev.device)
+    with torch.cuda.device(stream_dev.device):
+        _lib.check(L.vad_mfcc_delta_slices_f32(ctypes.c_void_p(stream_dev.data_ptr()),
+                                               ctypes.c_void_p(starts.data_ptr()), host.size - 1, n_frames,
+                                               int(np.diff(host).max()),
+                                               ctypes.c_void_p(out.data_ptr()), 24,
+                                               ctypes.c_void_p(out.data_ptr() + 12 * 4), 24, _lib.current_stream()))
     return out
 
 
@@ -150,6 +189,80 @@ def process_test_data(frames, labels):
         out['mfcc'][:count] = feat[:, :12]
         out['delta'][:count] = feat[:, 12:]
         out['labels'][:count] = lab[:count]
+    return out
+
+
+def training_slices(n_speech_frames, rng):
+    """The slice plan of process_training_data (core/process_data.py:82-108) for a speech set of
+    ``n_speech_frames`` labelled frames: random 33..166-frame cuts of the speech, as many frames again of
+    silence in random 33..166-frame pieces (marked ``(length, length)``), shuffled.  ``rng`` is the
+    ``numpy.random`` state the reference draws from (seeded with SEED at :76); the draw order is kept.
+    Returns (slices, total rows of the output datasets)."""
+    pos, slices = 0, []
+    while pos + SLICE_MIN < n_speech_frames:
+        cut = (pos, pos + rng.randint(SLICE_MIN, SLICE_MAX + 1))
+        slices.append(cut)
+        pos = cut[1]
+    slices[-1] = (slices[-1][0], n_speech_frames)                        # remainder joins the last slice (:93)
+    pos = 0
+    while pos + SLICE_MIN < n_speech_frames:
+        length = rng.randint(SLICE_MIN, SLICE_MAX + 1)
+        slices.append((length, length))
+        pos += length
+    total = n_speech_frames + pos + MFCC_WINDOW_FRAME_SIZE
+    rng.shuffle(slices)
+    return slices, total
+
+
+def process_training_data(speech_frames, speech_labels, noise_frames, seed=SEED):
+    """In-memory form of process_training_data (core/process_data.py:64-168): the speech set is cut into random
+    slices, silence slices are mixed in, every slice gets a random stretch of the noise set, and for each noise
+    level in NOISE_LEVELS_DB order add_noise is called once per slice with the previous 3 output frames of that
+    level as alignment rows.  Here the slices of a level are laid out as one stream on the device and the level
+    takes ONE overlay launch and ONE front-end launch.
+
+    Kept as the reference computes it (:139-153): inside the slice loop ``frames`` is overwritten by add_noise's
+    result, so the second and third level mix the noise into the PREVIOUS level's output, not into the clean
+    speech.  Returns a dict laid out like the HDF5 datasets the loop fills: ``frames-<key>`` (int16), ``mfcc-<key>``,
+    ``delta-<key>`` (float32) for key in NOISE_LEVELS_DB, ``labels`` (int8), each ``total`` rows of which the
+    first ``count`` are written, plus ``slices``."""
+    speech = _as_frames(speech_frames, 'speech_frames')
+    noise = _as_frames(noise_frames, 'noise_frames')
+    labels = np.asarray(speech_labels)
+    if len(labels) != len(speech):
+        raise ValueError('speech_labels has %d entries, speech_frames %d' % (len(labels), len(speech)))
+    if len(speech) <= SLICE_MIN:
+        raise ValueError('the speech set needs more than %d frames' % SLICE_MIN)
+    rng = np.random.RandomState(seed)                                     # np.random.seed(SEED), :76
+    slices, total = training_slices(len(speech), rng)
+    lengths = [s[0] if s[0] == s[1] else s[1] - s[0] for s in slices]
+    starts = np.concatenate(([0], np.cumsum(lengths))).astype(np.int64)
+    count = int(starts[-1])
+    clean = np.zeros((count, FRAME_SIZE), np.int16)
+    mixin = np.zeros((count, FRAME_SIZE), np.int16)
+    lab = np.zeros((count,), np.int8)
+    for s, lo, n in zip(slices, starts[:-1], lengths):
+        if s[0] != s[1]:                                                  # speech; silence stays zero (:126-132)
+            clean[lo: lo + n] = speech[s[0]: s[1]]
+            lab[lo: lo + n] = labels[s[0]: s[1]]
+        i = rng.randint(0, len(noise) - n)                                # :135
+        mixin[lo: lo + n] = noise[i: i + n]
+    dev = _device()
+    noise_dev = torch.from_numpy(mixin.reshape(-1)).to(dev)
+    prev = torch.from_numpy(clean.reshape(-1)).to(dev)
+    starts_dev = torch.from_numpy(starts).to(dev)
+    out = {'labels': np.zeros((total,), np.int8), 'count': count, 'slices': slices}
+    out['labels'][:count] = lab
+    for key, gain in NOISE_LEVELS_DB.items():
+        stream = torch.zeros((count + ALIGN_FRAMES) * FRAME_SIZE, dtype=torch.int16, device=dev)   # zero lead-in, :143
+        mixed = stream[ALIGN_FRAMES * FRAME_SIZE:]
+        overlay_device(noise_dev, prev, gain, out=mixed)
+        feat = mfcc_delta_ragged(stream, starts_dev).cpu().numpy()
+        for name, dtype, width, val in (('frames-', np.int16, FRAME_SIZE, mixed.cpu().numpy().reshape(-1, FRAME_SIZE)),
+                                        ('mfcc-', np.float32, 12, feat[:, :12]), ('delta-', np.float32, 12, feat[:, 12:])):
+            out[name + key] = np.zeros((total, width), dtype)
+            out[name + key][:count] = val
+        prev = mixed
     return out
 
 
