@@ -73,7 +73,7 @@ FLOP_PER_WINDOW = {               # model -> (algorithmic for stride-1 windows, 
 # the kernel that scores stride-1 windows of each model, as rocprofv3 names it (template arguments included)
 MODEL_KERNEL = {'gru_large': 'rnn_stream_kernel<false, true, 15>', 'gru_small': 'rnn_stream_kernel<false, false, 15>',
                 'lstm_large': 'rnn_stream_kernel<true, true, 15>', 'lstm_small': 'rnn_stream_kernel<true, false, 15>',
-                'gru_h90': 'gru_wide_kernel<true, 3>',
+                'gru_h90': 'gru_wide_stream_kernel<true, 3, 13>',
                 'densenet': 'densenet_stream_kernel<false>', 'densenet_large': 'densenet_stream_kernel<true>'}
 
 

@@ -179,6 +179,24 @@ int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t wind
                              void* stream);
 
 /*
+ * vad_gru_forward_f32 with a workspace, for GRUs with more than 32 hidden units (the enlarged ~100k-parameter
+ * configuration, hidden = 90; no class in the reference) over stride-1 windows (window_stride == 24).  The head
+ * of every step's accumulation chain, bias + W_ih x_row, depends on the feature row only; with a workspace
+ * it is computed once per row instead of once per window and step (the recurrent weights of such a model fill
+ * the LDS, so unlike the 30-unit models' kernel it cannot keep the projected rows on chip).  Results are
+ * bit-identical to vad_gru_forward_f32; other models and strides ignore the workspace.
+ *   workspace_dev    caller-owned device memory, 16-byte aligned; any size: the windows are processed in chunks
+ *                    of as many as the workspace has rows for (384 floats per row for hidden 65..96, 256 for
+ *                    33..64; at least 30 rows, else the workspace is not used).  Contents are scratch.
+ * vad_gru_workspace_bytes: the size that takes n_windows windows in one chunk (0 where no workspace is used).
+ */
+size_t vad_gru_workspace_bytes(int hidden, int64_t n_windows);
+int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                           const float* blob_dev, int hidden, int large,
+                           float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/*
  * How the stride-1 (window_stride == 24) GRU / LSTM kernels with hidden <= 32 form the float32 products
  * of the recurrence and of the 26-row head.  Process-wide; no counterpart in the reference.
  *   VAD_MATRIX_F32     v_mfma_f32_32x32x2_f32: a float32 FMA chain (default).

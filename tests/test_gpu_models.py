@@ -137,6 +137,52 @@ def test_gru_other_hidden_sizes(vad, hidden, large):
     assert torch.equal(ps, pb)
 
 
+@pytest.mark.parametrize('hidden,large', [(90, True), (64, False), (40, True)])
+def test_wide_gru_workspace_chunks(vad, hidden, large):
+    """vad_gru_forward_ws_f32: the stride-1 path of wide GRUs projects each feature row once into a caller-owned
+    workspace.  Whatever the workspace size (one chunk, several ragged chunks, too small to be used at all) the
+    posteriors equal those of the plain entry point bit for bit."""
+    import ctypes
+    from voice_activity_detection_amd import _lib
+    L = vad.lib()
+    ref = models_ref.make_model('gru_large' if large else 'gru_small', hidden=hidden)
+    net = vad.Net(large=large, lstm=False, hidden=hidden)
+    net.load_state_dict(ref.state_dict())
+    n_rows = 1000
+    feat = (torch.randn(n_rows, 24, generator=torch.Generator().manual_seed(3)) * 3.0).cuda()
+    n = n_rows - 29
+    blob = net._weights_on(feat.device)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    want_p = torch.empty(n, 2, device='cuda')
+    want_d = torch.empty(n, dtype=torch.uint8, device='cuda')
+    _lib.check(L.vad_gru_forward_f32(ptr(feat), n, 24, ptr(blob), hidden, int(large), ptr(want_p), ptr(want_d), 0,
+                                     ctypes.c_float(0.0), _lib.current_stream()))
+    with torch.no_grad():
+        y = ref(torch.from_numpy(pipeline_ref.windows(feat.cpu().numpy()))).numpy()
+    assert np.abs(want_p.cpu().numpy() - y).max() <= ATOL
+    row_bytes = 3 * ((hidden + 31) // 32) * 32 * 4
+    full = L.vad_gru_workspace_bytes(hidden, n)
+    assert full == n_rows * row_bytes
+    for ws_bytes in (full, full + 4096, 300 * row_bytes + 100, 31 * row_bytes, 29 * row_bytes, 0):
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device='cuda')
+        got_p = torch.full((n, 2), float('nan'), device='cuda')
+        got_d = torch.full((n,), 7, dtype=torch.uint8, device='cuda')
+        _lib.check(L.vad_gru_forward_ws_f32(ptr(feat), n, 24, ptr(blob), hidden, int(large), ptr(got_p), ptr(got_d), 0,
+                                            ctypes.c_float(0.0), ptr(ws) if ws_bytes else None, ws_bytes,
+                                            _lib.current_stream()))
+        assert torch.equal(got_p, want_p) and torch.equal(got_d, want_d), ws_bytes
+    # other strides and the reference's 30-unit model ignore the workspace
+    ws = torch.empty(full, dtype=torch.uint8, device='cuda')
+    x = feat[: 30 * 33].reshape(33, 30, 24).contiguous()
+    a, b = torch.empty(33, 2, device='cuda'), torch.empty(33, 2, device='cuda')
+    _lib.check(L.vad_gru_forward_f32(ptr(x), 33, 720, ptr(blob), hidden, int(large), ptr(a), None, 0,
+                                     ctypes.c_float(0.0), _lib.current_stream()))
+    _lib.check(L.vad_gru_forward_ws_f32(ptr(x), 33, 720, ptr(blob), hidden, int(large), ptr(b), None, 0,
+                                        ctypes.c_float(0.0), ptr(ws), full, _lib.current_stream()))
+    assert torch.equal(a, b)
+    assert L.vad_gru_workspace_bytes(30, 1000) == 0
+
+
 def test_lstm_wide_hidden_is_rejected(vad):
     net = vad.Net(large=False, lstm=True, hidden=64)
     with pytest.raises(vad.VadError):

@@ -311,11 +311,119 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
 }
 
 // ---------------------------------------------------------------------------------------------
-// GRU with 33..96 hidden units (UT = 2 or 3 unit tiles), any window stride.  Same cell as rnn_kernel,
-// one 32-unit tile of the new state at a time: the accumulators of a tile (r, z, n-input, n-hidden)
-// see the whole previous state as B operand, so the new state is double-buffered in registers.
+// GRU with 33..96 hidden units (UT = 2 or 3 unit tiles).  Same cell as rnn_kernel, one 32-unit tile of the new
+// state at a time: the accumulators of a tile (r, z, n-input, n-hidden) see the whole previous state as B
+// operand, so the new state is double-buffered in registers.  KL = k-steps of the last tile that carry units
+// (13 for hidden 90); its other k-steps multiply padding and are skipped.
+//   gru_wide_kernel         any window stride; the input projection is part of each step's chain.
+//   gru_wide_stream_kernel  stride-1 windows: the chain's head, bias + W_ih x_row, depends on the feature row
+//                           only and is shared by up to 30 windows.  row_project_kernel computes it once per row
+//                           into a caller-provided workspace (the weights fill the LDS, so it cannot stay on
+//                           chip as in rnn_stream_kernel) and the steps load their accumulators from there, one
+//                           tile ahead of the matrix work.  Bit-identical to gru_wide_kernel.
 
-template <bool LARGE, int UT>
+template <int UT, int KL>
+__device__ __forceinline__ constexpr int wide_ks(int kt) { return kt == UT - 1 ? KL : kHk; }
+
+// Recurrent A operands of the wide kernels in LDS: for gate g, unit tile mt and k-tile kt the four k-steps
+// 4 grp .. 4 grp + 3 of a lane are one 16-byte entry, entry index ((g UT + mt) UT 4 + kt 4 + grp) 64 + lane
+// (vad_pack_net_weights writes this order for hidden > 32).  The table exceeds the 64 KB an LDS instruction's
+// immediate offset spans, so it is addressed from two lane bases.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f32x4* lds_f4_ptr;       // a 32-bit LDS address
+
+struct WideA {
+    lds_f4_ptr lo;        // entries 0 .. 63 of every lane
+    lds_f4_ptr hi;        // entries 64 ..
+};
+
+__device__ __forceinline__ WideA wide_a(const float* a_hh, int lane) {
+    WideA a;
+    a.lo = (lds_f4_ptr)a_hh + lane;
+    unsigned hi = (unsigned)(__UINTPTR_TYPE__)(a.lo + 64 * 64);
+    asm volatile("" : "+v"(hi));                        // a base of its own, not lo + a constant recomputed per read
+    a.hi = (lds_f4_ptr)(__UINTPTR_TYPE__)hi;
+    return a;
+}
+
+template <int UT>
+__device__ __forceinline__ f32x4 wide_a_entry(const WideA& a, int g, int mt, int kt, int grp) {
+    const int c = (g * UT + mt) * UT * 4 + kt * 4 + grp;
+    return c < 64 ? a.lo[c * 64] : a.hi[(c - 64) * 64];
+}
+
+// Step t's tile mt from its four accumulators: recurrent product, gate math.  The A operands of the next
+// group of four k-steps are read while the matrix cores work on the current one.
+template <int UT, int KL>
+__device__ __forceinline__ void wide_tile_step(f32x16 (&acc)[4], const f32x16 (&h)[UT], f32x16& hn_mt, const f32x16& h_mt,
+                                               const WideA& a, int mt, int t) {
+    if (t > 0) {
+        f32x4 cur[3], nxt[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) cur[g] = wide_a_entry<UT>(a, g, mt, 0, 0);
+#pragma unroll
+        for (int kt = 0; kt < UT; ++kt) {
+            constexpr int kGroups = 4;
+#pragma unroll
+            for (int grp = 0; grp < kGroups; ++grp) {
+                if (4 * grp >= wide_ks<UT, KL>(kt)) continue;
+                // the group after this one: next group of the k-tile, or the first of the next k-tile
+                const bool more_here = 4 * (grp + 1) < wide_ks<UT, KL>(kt);
+                if (more_here || kt + 1 < UT) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        nxt[g] = wide_a_entry<UT>(a, g, mt, more_here ? kt : kt + 1, more_here ? grp + 1 : 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);           // the reads above go out before this group's matrix work
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * grp + q;
+                    if (i >= wide_ks<UT, KL>(kt)) continue;
+                    const float hv = h[kt][i];
+                    acc[0] = MFMA(cur[0][q], hv, acc[0]);
+                    acc[1] = MFMA(cur[1][q], hv, acc[1]);
+                    acc[3] = MFMA(cur[2][q], hv, acc[3]);
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) cur[g] = nxt[g];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float r = sigmoid_pre(acc[0][i]);
+        const float z = sigmoid_pre(acc[1][i]);
+        const float n = tanh_pre(fmaf(r, acc[3][i], acc[2][i]));
+        hn_mt[i] = fmaf(z, h_mt[i] - n, n);
+    }
+}
+
+// The step-t slice of the 26-row (or 2-row) head for the wide models.  Its A operands come from the weight
+// blob in global memory (L2): all of the step's loads are issued before the first product waits for one (left
+// to itself the compiler issues them one at a time, each behind the product that uses the previous one).
+template <int UT, int KL>
+__device__ __forceinline__ void wide_head_step(f32x16& lacc, const f32x16 (&h)[UT], const float* __restrict__ a1, int t, int lane) {
+    constexpr int kSteps = (UT - 1) * kHk + KL;
+    float aw[kSteps];
+    {
+        int j = 0;
+#pragma unroll
+        for (int kt = 0; kt < UT; ++kt)
+#pragma unroll
+            for (int i = 0; i < wide_ks<UT, KL>(kt); ++i) aw[j++] = a1[(t * UT * kHk + kt * kHk + i) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        int j = 0;
+#pragma unroll
+        for (int kt = 0; kt < UT; ++kt)
+#pragma unroll
+            for (int i = 0; i < wide_ks<UT, KL>(kt); ++i) lacc = MFMA(aw[j++], h[kt][i], lacc);
+    }
+}
+
+template <bool LARGE, int UT, int KL>
 __global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restrict__ x, long n_windows, WindowMap wm,
                                                           const float* __restrict__ blob, float* __restrict__ p_out,
                                                           uint8_t* __restrict__ dec_out, int mode, float threshold) {
@@ -336,6 +444,7 @@ __global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restric
     if (tile * kWindowsPerWave >= n_windows) return;
     const long wc = w < n_windows ? w : n_windows - 1;
     const float* xw = window_ptr(x, wm, wc) + 12 * half;
+    const WideA wa = wide_a(a_hh, lane);
 
     f32x16 h[UT], hn[UT], lacc;
 #pragma unroll
@@ -360,36 +469,119 @@ __global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restric
             for (int sft = 0; sft < kKs; ++sft)
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[g] = MFMA(a_ih[((g * UT + mt) * kKs + sft) * 64 + lane], xv[sft], acc[g]);
-            if (t > 0) {
+            wide_tile_step<UT, KL>(acc, h, hn[mt], h[mt], wa, mt, t);
+        }
 #pragma unroll
-                for (int kt = 0; kt < UT; ++kt) {
-                    __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < UT; ++u) h[u] = hn[u];
+        __builtin_amdgcn_sched_barrier(0);
+        wide_head_step<UT, KL>(lacc, h, a1, t, lane);
+    }
+    head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
+}
+
+// gi[row][(g * UT + mt) * 32 + half * 16 + i] = accumulator register i of lane (row, half) after bias + W_ih x_row
+// for gate g (r, z, n-input), unit tile mt: exactly the registers a step of the stream kernel starts from.
+template <int UT>
+__global__ __launch_bounds__(256) void row_project_kernel(const float* __restrict__ feat, long n_rows,
+                                                          const float* __restrict__ blob, float* __restrict__ gi) {
+    const NetLayout L = net_layout(false, false, UT);            // a_ih and cb do not depend on the head
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + col;
+    if (row - col >= n_rows) return;                             // wave-uniform
+    const long rc = row < n_rows ? row : n_rows - 1;
+    const float* xr = feat + rc * kF + 12 * half;
+    const float4 xa = *reinterpret_cast<const float4*>(xr), xb = *reinterpret_cast<const float4*>(xr + 4),
+                 xc = *reinterpret_cast<const float4*>(xr + 8);
+    const float xv[12] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w, xc.x, xc.y, xc.z, xc.w};
+    float* dst = gi + rc * (3 * UT * 32) + half * 16;
 #pragma unroll
-                    for (int i = 0; i < kHk; ++i) {
-                        const float hv = h[kt][i];
-                        const int ks = kt * kHk + i;
-                        acc[0] = MFMA(a_hh[((0 * UT + mt) * UT * kHk + ks) * 64 + lane], hv, acc[0]);
-                        acc[1] = MFMA(a_hh[((1 * UT + mt) * UT * kHk + ks) * 64 + lane], hv, acc[1]);
-                        acc[3] = MFMA(a_hh[((2 * UT + mt) * UT * kHk + ks) * 64 + lane], hv, acc[3]);
-                    }
-                }
-            }
+    for (int gm = 0; gm < 3 * UT; ++gm) {
+        f32x16 acc = load16(blob + L.cb + (gm * 2 + half) * 16);
+#pragma unroll
+        for (int s = 0; s < kKs; ++s) acc = MFMA(blob[L.a_ih + (gm * kKs + s) * 64 + lane], xv[s], acc);
+        if (row < n_rows) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(dst + gm * 32 + 4 * q) =
+                    make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+    }
+}
+
+// Lane l takes the value of lane l + 1 (whole-wave shift by one lane, no LDS traffic); lane 63 keeps its own.
+__device__ __forceinline__ float lane_up(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+}
+
+// A lane (window column `col`, half) holds the projected row its window consumes at the current step in
+// registers, 3 * UT tiles of 16.  Window w + 1 consumes at step t the row that window w consumes at step t + 1,
+// so from one step to the next the rows move down by one lane and only the wave's last column loads a new
+// one: the workspace is read once per row and wave (plus 29 rows of overlap per 32 windows) instead of 30 times.
+template <bool LARGE, int UT, int KL>
+__global__ __launch_bounds__(256, 1) void gru_wide_stream_kernel(const float* __restrict__ gi, long n_windows,
+                                                                 const float* __restrict__ blob, float* __restrict__ p_out,
+                                                                 uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    extern __shared__ __align__(16) float lds[];
+    const NetLayout L = net_layout(false, LARGE, UT);
+    // the recurrent A operands and the biases (the input projection's operands are not needed here)
+    for (int i = L.a_hh + threadIdx.x; i < L.head; i += blockDim.x) lds[i - L.a_hh] = blob[i];
+    __syncthreads();
+    const float* a_hh = lds;
+    const float* cb = lds + (L.cb - L.a_hh);
+    const float* a1 = blob + L.head;
+
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const long tile = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long w = tile * kWindowsPerWave + col;
+    if (tile * kWindowsPerWave >= n_windows) return;
+    const long last_row = n_windows + kT - 2;                    // the workspace holds n_windows + 29 rows
+    constexpr int kRow = 3 * UT * 32;                            // floats per projected row
+    const WideA wa = wide_a(a_hh, lane);
+
+    f32x16 h[UT], hn[UT], lacc, row[3 * UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[u][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.0f;
+    {
+        const float* src = gi + (w < last_row ? w : last_row) * kRow + half * 16;      // step 0: row w
+#pragma unroll
+        for (int gm = 0; gm < 3 * UT; ++gm) row[gm] = load16(src + gm * 32);
+    }
+
+    for (int t = 0; t < kT; ++t) {
+        // the row the wave's last column consumes at the next step
+        const long rn = tile * kWindowsPerWave + 31 + t + 1;
+        const float* nxt = gi + (rn < last_row ? rn : last_row) * kRow + half * 16;
+#pragma unroll
+        for (int mt = 0; mt < UT; ++mt) {
             __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float r = sigmoid_pre(acc[0][i]);
-                const float z = sigmoid_pre(acc[1][i]);
-                const float n = tanh_pre(fmaf(r, acc[3][i], acc[2][i]));
-                hn[mt][i] = fmaf(z, h[mt][i] - n, n);
+            for (int g = 0; g < 3; ++g) acc[g] = row[g * UT + mt];
+            acc[3] = load16(cb + ((3 * UT + mt) * 2 + half) * 16);
+            wide_tile_step<UT, KL>(acc, h, hn[mt], h[mt], wa, mt, t);
+            if (t + 1 < kT) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    f32x16 v;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = lane_up(row[g * UT + mt][i]);
+                    if (col == 31) v = load16(nxt + (g * UT + mt) * 32);       // in flight until the next step
+                    row[g * UT + mt] = v;
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < UT; ++u) h[u] = hn[u];
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kt = 0; kt < UT; ++kt)
-#pragma unroll
-            for (int i = 0; i < kHk; ++i) lacc = MFMA(a1[(t * UT * kHk + kt * kHk + i) * 64 + lane], h[kt][i], lacc);
+        wide_head_step<UT, KL>(lacc, h, a1, t, lane);
     }
     head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
 }
@@ -399,6 +591,14 @@ int allow_lds(K kernel, int floats) {
     VAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       floats * (int)sizeof(float)));
     return VAD_OK;
+}
+
+template <bool LARGE, int UT, int KL>
+int allow_wide() {
+    const NetLayout L = net_layout(false, LARGE, UT);
+    int rc = allow_lds(&gru_wide_kernel<LARGE, UT, KL>, L.head);
+    if (rc != VAD_OK) return rc;
+    return allow_lds(&gru_wide_stream_kernel<LARGE, UT, KL>, L.head - L.a_hh);
 }
 
 }  // namespace
@@ -429,30 +629,66 @@ int ensure_rnn_attrs() {
     if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 9>, SplitCfg<false>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 9>, SplitCfg<true>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_split_kernel<true, true, 9>, SplitCfg<true>::lds_floats))) return rc;
-    if ((rc = allow_lds(&gru_wide_kernel<false, 2>, net_layout(false, false, 2).head))) return rc;
-    if ((rc = allow_lds(&gru_wide_kernel<true, 2>, net_layout(false, true, 2).head))) return rc;
-    if ((rc = allow_lds(&gru_wide_kernel<false, 3>, net_layout(false, false, 3).head))) return rc;
-    if ((rc = allow_lds(&gru_wide_kernel<true, 3>, net_layout(false, true, 3).head))) return rc;
+    if ((rc = allow_wide<false, 2, 13>()) || (rc = allow_wide<true, 2, 13>()) || (rc = allow_wide<false, 3, 13>()) ||
+        (rc = allow_wide<true, 3, 13>()) || (rc = allow_wide<false, 2, 16>()) || (rc = allow_wide<true, 2, 16>()) ||
+        (rc = allow_wide<false, 3, 16>()) || (rc = allow_wide<true, 3, 16>()))
+        return rc;
     done[dev] = true;
     return VAD_OK;
 }
 
 namespace {
 
-template <bool LARGE, int UT>
+// Scratch of the stride-1 wide GRU: one projected row (3 gates x UT tiles x 32 floats) per feature row of a chunk.
+struct Workspace {
+    float* ptr;
+    size_t bytes;
+};
+
+template <bool LARGE, int UT, int KL>
 int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec, int mode,
-                float threshold, hipStream_t st) {
+                float threshold, Workspace ws, hipStream_t st) {
     const NetLayout L = net_layout(false, LARGE, UT);
-    const size_t lds_bytes = (size_t)L.head * sizeof(float);
     int rc = ensure_rnn_attrs();
     if (rc != VAD_OK) return rc;
     const long per_block = (long)kWindowsPerWave * kWavesPerBlock;
+    const size_t row_bytes = (size_t)3 * UT * 32 * sizeof(float);
+    const long ws_rows = ws.ptr ? (long)(ws.bytes / row_bytes) : 0;
+    if (!wm.rows && wm.stride == kF && ws_rows >= kT) {
+        // stride-1 windows: chunks of as many windows as the workspace has rows for; the projection of a chunk's
+        // rows, then its windows (stream order makes the rows visible to the second kernel and keeps the next
+        // chunk's projection from overwriting rows still in use)
+        const long chunk = ws_rows - (kT - 1);
+        const size_t lds_bytes = (size_t)(L.head - L.a_hh) * sizeof(float);
+        for (long w0 = 0; w0 < n_windows; w0 += chunk) {
+            const long nw = n_windows - w0 < chunk ? n_windows - w0 : chunk;
+            const long rows = nw + kT - 1;
+            const long pblocks = (rows + 127) / 128, blocks = (nw + per_block - 1) / per_block;
+            VAD_REQUIRE(pblocks <= 0x7FFFFFFFL && blocks <= 0x7FFFFFFFL, "too many windows for one launch");
+            hipLaunchKernelGGL((row_project_kernel<UT>), dim3((unsigned)pblocks), dim3(256), 0, st, x + w0 * kF, rows, blob,
+                               ws.ptr);
+            hipLaunchKernelGGL((gru_wide_stream_kernel<LARGE, UT, KL>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
+                               lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+            VAD_HIP_CHECK(hipGetLastError());
+        }
+        return VAD_OK;
+    }
+    const size_t lds_bytes = (size_t)L.head * sizeof(float);
     const long blocks = (n_windows + per_block - 1) / per_block;
     VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
-    hipLaunchKernelGGL((gru_wide_kernel<LARGE, UT>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds_bytes, st, x,
+    hipLaunchKernelGGL((gru_wide_kernel<LARGE, UT, KL>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock), lds_bytes, st, x,
                        n_windows, wm, blob, p, dec, mode, threshold);
     VAD_HIP_CHECK(hipGetLastError());
     return VAD_OK;
+}
+
+template <bool LARGE, int UT>
+int launch_wide_kl(int hidden, const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec,
+                   int mode, float threshold, Workspace ws, hipStream_t st) {
+    // k-steps of the last tile that carry units; the two instantiations cover hidden 90 (13) and everything else
+    return tile_k_steps(tile_units(hidden, UT - 1)) <= 13
+               ? launch_wide<LARGE, UT, 13>(x, n_windows, wm, blob, p, dec, mode, threshold, ws, st)
+               : launch_wide<LARGE, UT, 16>(x, n_windows, wm, blob, p, dec, mode, threshold, ws, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -504,7 +740,7 @@ int launch_ks(const float* x, long n_windows, WindowMap wm, const float* blob, f
 template <bool LSTM, bool LARGE>
 int launch(const float* x, long n_windows, WindowMap wm, const float* blob, int hidden, float* p, uint8_t* dec, int mode,
            float threshold, hipStream_t st) {
-    return hidden_k_steps(hidden) == kHk - 1
+    return hidden_k_steps(hidden) <= kHk - 1
                ? launch_ks<LSTM, LARGE, kHk - 1>(x, n_windows, wm, blob, p, dec, mode, threshold, st)
                : launch_ks<LSTM, LARGE, kHk>(x, n_windows, wm, blob, p, dec, mode, threshold, st);
 }
@@ -512,7 +748,8 @@ int launch(const float* x, long n_windows, WindowMap wm, const float* blob, int 
 }  // namespace
 
 int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, const float* blob, int hidden, int large,
-                float* p, uint8_t* dec, int mode, float threshold, void* stream) {
+                float* p, uint8_t* dec, int mode, float threshold, void* stream, float* ws_ptr = nullptr,
+                size_t ws_bytes = 0) {
     const long wstride = wm.stride;
     VAD_REQUIRE(x && blob && p, "null pointer argument");
     VAD_REQUIRE(hidden >= 1 && hidden <= (lstm ? kHp : 3 * kHp),
@@ -529,12 +766,13 @@ int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, cons
         return large ? launch<true, true>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st)
                      : launch<true, false>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st);
     }
+    const Workspace ws{ws_ptr, ws_bytes};
     if (hidden > 2 * kHp)
-        return large ? launch_wide<true, 3>(x, n_windows, wm, blob, p, dec, mode, threshold, st)
-                     : launch_wide<false, 3>(x, n_windows, wm, blob, p, dec, mode, threshold, st);
+        return large ? launch_wide_kl<true, 3>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, st)
+                     : launch_wide_kl<false, 3>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, st);
     if (hidden > kHp)
-        return large ? launch_wide<true, 2>(x, n_windows, wm, blob, p, dec, mode, threshold, st)
-                     : launch_wide<false, 2>(x, n_windows, wm, blob, p, dec, mode, threshold, st);
+        return large ? launch_wide_kl<true, 2>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, st)
+                     : launch_wide_kl<false, 2>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, st);
     return large ? launch<false, true>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st)
                  : launch<false, false>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st);
 }
@@ -571,7 +809,10 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
     const int H = hidden, G = L.gates, KH = UT * kHk;
     memset(blob, 0, sizeof(float) * (size_t)L.total);
     // tile row -> hidden unit (-1 = padding).  One-tile models may skip the all-padding k-step.
-    auto unit_at = [&](int tile, int r) { return UT == 1 ? unit_of_row(r, H) : (32 * tile + r < H ? 32 * tile + r : -1); };
+    auto unit_at = [&](int tile, int r) {
+        const int u = unit_of_tile_row(r, tile_units(H, tile));
+        return u < 0 ? -1 : 32 * tile + u;
+    };
     // gate scale: sigmoid gates -log2 e, tanh gates 2 log2 e (GRU r,z | n ; LSTM i,f,o | g)
     auto gate_scale = [&](int g) { return (lstm ? g == 2 : g == 2) ? kTanhScale : kSigmoidScale; };
     for (int g = 0; g < G; ++g)
@@ -585,8 +826,11 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
                         (float)(sc * (double)w_ih[(g * H + m) * kF + s + 12 * hh]);
                 for (int ks = 0; ks < KH; ++ks) {
                     const int u = unit_at(ks / kHk, mfma32_row(ks % kHk, hh));
-                    if (u >= 0)
-                        blob[L.a_hh + ((g * UT + mt) * KH + ks) * 64 + lane] = (float)(sc * (double)w_hh[(g * H + m) * H + u]);
+                    if (u < 0) continue;
+                    // one-tile models: k-step major; wider ones: groups of four k-steps per lane (WideA in rnn.hip)
+                    const int at = UT == 1 ? ((g * UT + mt) * KH + ks) * 64 + lane
+                                           : (((g * UT + mt) * KH + (ks & ~3)) * 64) + lane * 4 + (ks & 3);
+                    blob[L.a_hh + at] = (float)(sc * (double)w_hh[(g * H + m) * H + u]);
                 }
             }
     for (int mt = 0; mt < UT; ++mt)
@@ -668,6 +912,21 @@ extern "C" int vad_gru_forward_f32(const float* x_dev, int64_t n_windows, int64_
                                    float threshold, void* stream) {
     return vad::rnn_forward(false, x_dev, n_windows, vad::WindowMap{(long)window_stride, nullptr, 0}, blob_dev, hidden,
                             large, p_dev, decision_dev, decision_mode, threshold, stream);
+}
+
+extern "C" size_t vad_gru_workspace_bytes(int hidden, int64_t n_windows) {
+    if (hidden <= vad::kHp || hidden > 3 * vad::kHp || n_windows <= 0) return 0;
+    return (size_t)(n_windows + vad::kT - 1) * 3 * vad::unit_tiles(hidden) * 32 * sizeof(float);
+}
+
+extern "C" int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,
+                                      int hidden, int large, float* p_dev, uint8_t* decision_dev, int decision_mode,
+                                      float threshold, void* workspace_dev, size_t workspace_bytes, void* stream) {
+    using namespace vad;
+    VAD_REQUIRE(workspace_dev || workspace_bytes == 0, "null workspace with a non-zero size");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(workspace_dev) & 15) == 0, "workspace_dev must be 16-byte aligned");
+    return rnn_forward(false, x_dev, n_windows, WindowMap{(long)window_stride, nullptr, 0}, blob_dev, hidden, large, p_dev,
+                       decision_dev, decision_mode, threshold, stream, static_cast<float*>(workspace_dev), workspace_bytes);
 }
 
 extern "C" int vad_lstm_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,

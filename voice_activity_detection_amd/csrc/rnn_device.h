@@ -53,19 +53,26 @@ __host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 
 
 __host__ __device__ inline int unit_tiles(int hidden) { return (hidden + 31) / 32; }
 
-// Placement of the hidden units on the 32 rows of a tile.  Rows (i & 3) + 8 (i >> 2) + 4 hh of
-// k-step i = 15 are rows 27 and 31; when the hidden size leaves two rows free (H <= 30, the reference
-// uses 30) those two are the padding, k-step 15 multiplies zeros only and the kernels skip it.
-__host__ __device__ inline int hidden_k_steps(int hidden) { return hidden <= 30 ? kHk - 1 : kHk; }
-__host__ __device__ inline int row_of_unit(int u, int hidden) {
-    return (hidden <= 30 && u >= 27) ? u + 1 : u;            // skips row 27; row 31 is never reached
+// Placement of hidden units on the 32 rows of a tile.  K-step i of the next step's product takes rows
+// (i & 3) + 8 (i >> 2) and that + 4 as its two k values.  A tile that holds nu < 32 units puts them, in order,
+// on the rows of its first ceil(nu / 2) k-steps, so that the remaining k-steps multiply padding only and the
+// kernels skip them: nu = 30 (the reference's hidden size) leaves out rows 27 and 31 = k-step 15; the last
+// tile of hidden = 90 holds 26 units on rows 0..24 and 28 = k-steps 0..12.
+__host__ __device__ inline int tile_units(int hidden, int tile) {
+    const int n = hidden - 32 * tile;
+    return n > 32 ? 32 : (n < 0 ? 0 : n);
 }
-__host__ __device__ inline int unit_of_row(int r, int hidden) {
-    if (hidden > 30) return r < hidden ? r : -1;
-    if (r == 27 || r == 31) return -1;
-    const int u = r > 27 ? r - 1 : r;
-    return u < hidden ? u : -1;
+__host__ __device__ inline int tile_k_steps(int nu) { return (nu + 1) / 2; }
+__host__ __device__ inline int k_step_of_row(int r) { return (r & 3) + 4 * (r >> 3); }
+__host__ __device__ inline int unit_of_tile_row(int r, int nu) {     // unit index inside the tile, or -1 = padding
+    const int ks = tile_k_steps(nu);
+    if (k_step_of_row(r) >= ks) return -1;
+    int rank = 0;
+    for (int q = 0; q < r; ++q) rank += k_step_of_row(q) < ks ? 1 : 0;
+    return rank < nu ? rank : -1;
 }
+__host__ __device__ inline int hidden_k_steps(int hidden) { return tile_k_steps(tile_units(hidden, 0)); }   // one-tile models
+__host__ __device__ inline int unit_of_row(int r, int hidden) { return unit_of_tile_row(r, tile_units(hidden, 0)); }
 
 // The packer scales the sigmoid gates' weights and biases by -log2(e) and the tanh gates' by
 // 2 log2(e), so the pre-activations arrive ready for v_exp_f32 (2^x).

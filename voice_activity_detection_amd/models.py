@@ -178,9 +178,23 @@ class Net(_HipModule):
             hp(a['lin.weight']), hp(a['lin.bias']), hp(blob), n))
         return blob
 
+    # largest scratch the wide GRU's stride-1 path is given (bigger launches go in chunks)
+    WORKSPACE_CAP = 16 << 30
+
     def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+        H = self.rnn.hidden_size
+        if not self.lstm and H > 32 and stride == FEATURES:
+            # projected feature rows of the wide GRU live in a workspace this module owns (reused across calls)
+            need = min(L.vad_gru_workspace_bytes(H, n), self.WORKSPACE_CAP)
+            dev = torch.device('cuda', torch.cuda.current_device())
+            ws = getattr(self, '_ws', None)
+            if ws is None or ws.device != dev or ws.numel() < need:
+                self._ws = ws = None                    # release before growing
+                self._ws = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            return L.vad_gru_forward_ws_f32(x_ptr, n, stride, blob_ptr, H, int(self.large), p_ptr, d_ptr, mode, thr,
+                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream)
         fn = L.vad_lstm_forward_f32 if self.lstm else L.vad_gru_forward_f32
-        return fn(x_ptr, n, stride, blob_ptr, self.rnn.hidden_size, int(self.large), p_ptr, d_ptr, mode, thr, stream)
+        return fn(x_ptr, n, stride, blob_ptr, H, int(self.large), p_ptr, d_ptr, mode, thr, stream)
 
     def _launch_rows(self, L, f_ptr, n_rows, r_ptr, n, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
         fn = L.vad_lstm_forward_rows_f32 if self.lstm else L.vad_gru_forward_rows_f32
