@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 FRAMES_PER_HOUR = 120000          # 3600 s / 0.03 s
 T, F = 30, 24                     # steps per window, features per row
 PEAK_FP32_TFLOPS = 157.3          # dense fp32 matrix = fp32 vector (FMA) peak, MI355X
+PEAK_BF16_TFLOPS = 2500.0         # dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
 SIMDS = 256 * 4
 VALU_ISSUE_CYCLES = 2.0           # a wave64 vector instruction occupies its SIMD-32 for 2 cycles
@@ -75,6 +76,30 @@ MODEL_KERNEL = {'gru_large': 'rnn_stream_kernel<false, true, 15>', 'gru_small': 
                 'lstm_large': 'rnn_stream_kernel<true, true, 15>', 'lstm_small': 'rnn_stream_kernel<true, false, 15>',
                 'gru_h90': 'gru_wide_stream_kernel<true, 3, 13>',
                 'densenet': 'densenet_stream_kernel<false>', 'densenet_large': 'densenet_stream_kernel<true>'}
+
+
+def model_peak(model, mode):
+    """The float32 flop rate the hardware could sustain on a model's algorithmic work.  float32 MFMA and float32
+    vector work share one pipe (157.3 TF).  In the bf16 split modes of the 30-unit GRU / LSTM the recurrent and
+    26-row head products run as 9 (or 6) bf16 partial products each on the bf16 matrix pipe, beside the rest of
+    the work (projection, gate math, 2-row head) on the float32 pipe: the slower of the two pipes bounds it."""
+    if mode == 'f32' or not MODEL_KERNEL[model].startswith('rnn_stream_kernel'):
+        return PEAK_FP32_TFLOPS
+    gates = 4 if model.startswith('lstm') else 3
+    head_rows = 26 if model.endswith('large') else 0            # the 2-row head stays on the vector ALU
+    total = FLOP_PER_WINDOW[model][0]
+    on_bf16 = T * (30 * gates * 30 * 2 + 30 * head_rows * 2)
+    seconds = max(on_bf16 * int(mode[-1]) / (PEAK_BF16_TFLOPS * 1e12), (total - on_bf16) / (PEAK_FP32_TFLOPS * 1e12))
+    return total / seconds / 1e12
+
+
+def model_kernel(model, mode):
+    """Kernel name for a model under a matrix mode: the bf16 split modes apply to the 30-unit GRU / LSTM only."""
+    name = MODEL_KERNEL[model]
+    if mode != 'f32' and name.startswith('rnn_stream_kernel'):
+        lstm, large = name[name.index('<') + 1:].split(', ')[:2]
+        return 'rnn_stream_split_kernel<%s, %s, %s>' % (lstm, large, mode[-1])
+    return name
 
 
 # ---------------------------------------------------------------------------------------------
@@ -238,8 +263,10 @@ def main():
     ap.add_argument('--slice', type=int, default=166, help='frames per MFCC slice (reference test path: 166)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-configs', action='store_true', help='time the headline workload only')
-    ap.add_argument('--matrix-mode', default='f32', choices=['f32', 'bf16x6', 'bf16x9'],
-                    help='how the stride-1 GRU/LSTM kernels form float32 products (default: float32 MFMA)')
+    ap.add_argument('--matrix-mode', default='bf16x9', choices=['f32', 'bf16x6', 'bf16x9'],
+                    help="how the stride-1 GRU/LSTM kernels form float32 products (default: the library's default, "
+                         'bf16x9 = float32 operands split exactly into three bf16, all nine exact partial products '
+                         'accumulated in float32 on the bf16 matrix pipe)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -270,6 +297,7 @@ def main():
     from voice_activity_detection_amd.sharding import shard_plan
     pkg.init()
     pkg.set_matrix_mode(args.matrix_mode)
+    current_mode = [args.matrix_mode]
     prof = load_pmc_profile()
     free_bytes = torch.cuda.mem_get_info()[0]
 
@@ -335,17 +363,23 @@ def main():
         achieved = flop_alg * n_windows / (nn_ms * 1e-3) / 1e12
         # fp32 MFMA (v_mfma_f32_32x32x2_f32) issues at the fp32 vector FMA rate and does not co-execute with
         # vector instructions, so matrix and vector fp32 work share the one 157.3 TFLOP/s peak.
-        nn_pmc = pmc_per_unit(prof, MODEL_KERNEL[model])
+        kernel = model_kernel(model, current_mode[0])
+        nn_pmc = pmc_per_unit(prof, kernel)
         model_roof = {
-            'bound': 'mfma', 'kernel': MODEL_KERNEL[model], 'model': model,
-            'achieved': achieved, 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_TFLOPS,
+            'bound': 'mfma', 'kernel': kernel, 'model': model,
+            'matrix_mode': current_mode[0] if kernel != MODEL_KERNEL[model] else 'f32',
+            'achieved': achieved, 'peak': model_peak(model, current_mode[0]), 'unit': 'TFLOP/s',
+            'frac': achieved / model_peak(model, current_mode[0]), 'frac_of_fp32_peak': achieved / PEAK_FP32_TFLOPS,
             'traffic': nn_pmc['bytes_per_unit'] * n_windows if nn_pmc and 'bytes_per_unit' in nn_pmc else None,
             'traffic_from_profile': nn_pmc, 'ms_per_launch': nn_ms,
             'algorithmic_bytes': (F * 4 + RESULT_BYTES_PER_WINDOW) * n_windows,
             'flop_per_window': flop_alg, 'flop_per_window_pytorch': flop_torch, 'windows_per_launch': n_windows,
-            'note': 'achieved = algorithmic flops / time, with the per-row work (input projection / DenseNet stem) '
-                    'counted once per feature row as stride-1 windows need it; flop_per_window_pytorch counts it '
-                    'per (30,24) window as a batch framework does'}
+            'note': 'achieved = algorithmic float32 flops / time, with the per-row work (input projection / DenseNet '
+                    'stem) counted once per feature row as stride-1 windows need it; flop_per_window_pytorch counts '
+                    'it per (30,24) window as a batch framework does.  peak: 157.3 TF (fp32 MFMA = fp32 vector rate) '
+                    'for float32-MFMA kernels; in the bf16x9 / bf16x6 matrix modes every float32 product of the '
+                    'recurrence and the 26-row head costs 9 / 6 bf16 products, so the peak for that work is '
+                    '2500 TF / 9 (or 6), taken beside the float32 pipe for the rest'}
         fe_gbs = FRONTEND_BYTES_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e9
         fe_tf = FRONTEND_FLOP_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e12
         fe_pmc = pmc_per_unit(prof, 'mfcc_kernel')
@@ -389,7 +423,7 @@ def main():
                'config': head['config'], 'x_realtime_per_gpu': head['x_realtime_per_gpu'],
                'roofline': head['roofline'], 'kernels': head['kernels'], 'matrix_mode': args.matrix_mode}
 
-    if not args.no_configs and args.model == 'gru_large' and args.matrix_mode == 'f32':
+    if not args.no_configs and args.model == 'gru_large' and args.matrix_mode == 'bf16x9':
         # The other configurations of the measurement plan, 3 steps each on the buffers of the headline run:
         # LSTM-small, DenseNet small and large, and the enlarged GRU (hidden 90).  With 8 ranks the enlarged
         # GRU runs at its named size, 10 000 h over the node = 1 250 h (144 GB of int16) per GPU.
@@ -404,23 +438,26 @@ def main():
         if rank == 0:
             out['configs'] = extra
 
-    if rank == 0 and world == 1 and args.matrix_mode == 'f32' and \
+    if rank == 0 and world == 1 and args.matrix_mode == 'bf16x9' and \
             args.model in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
-        # Not part of `value`: the same step with the recurrent and head products on the bf16 matrix pipe
-        # (float32 operands split exactly into three bf16; vad_set_matrix_mode), and how far its posteriors
-        # are from the float32-MFMA ones over every window of the workload.
-        rec, buffers = run_workload(args.model, args.hours, 1, 1, buffers)
-        _, stream, ws = buffers
-        p_f32 = ws.p.clone()
-        alt = {}
-        for mm in ('bf16x9', 'bf16x6'):
+        # Not part of `value`: the same step in the other matrix modes of the stride-1 GRU / LSTM kernels
+        # (vad_set_matrix_mode) -- the float32 MFMA (a k-ordered FMA chain) and bf16x6 -- and how far the
+        # posteriors of each mode are from the float32-MFMA ones over every window of the workload.
+        alt, ps = {}, {}
+        for mm in ('f32', 'bf16x9', 'bf16x6'):
             pkg.set_matrix_mode(mm)
+            current_mode[0] = mm
             rec, buffers = run_workload(args.model, args.hours, 3, 1, buffers)
+            ps[mm] = buffers[2].p.clone()
             alt[mm] = {'value': rec['value'], 'unit': 'audio-hours/s', 'ms_per_step': rec['ms_per_step'],
-                       'max_abs_posterior_diff_vs_f32': float((ws.p - p_f32).abs().max())}
-        pkg.set_matrix_mode('f32')
-        out['alt_matrix_modes'] = alt
-        del p_f32
+                       'model_kernel_ms': rec['kernels']['model']['ms_per_launch'],
+                       'model_kernel_frac': rec['kernels']['model']['frac']}
+        for mm in alt:
+            alt[mm]['max_abs_posterior_diff_vs_f32'] = float((ps[mm] - ps['f32']).abs().max())
+        pkg.set_matrix_mode(args.matrix_mode)
+        current_mode[0] = args.matrix_mode
+        out['matrix_modes'] = alt
+        del ps
     if rank == 0:
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(args.model)

@@ -199,11 +199,14 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
 /*
  * How the stride-1 (window_stride == 24) GRU / LSTM kernels with hidden <= 32 form the float32 products
  * of the recurrence and of the 26-row head.  Process-wide; no counterpart in the reference.
- *   VAD_MATRIX_F32     v_mfma_f32_32x32x2_f32: a float32 FMA chain (default).
- *   VAD_MATRIX_BF16X9  every float32 operand is split exactly into three bfloat16 and all nine partial
- *                      products are accumulated in float32 on the bf16 matrix pipe: the products are
- *                      exact, only the float32 accumulation rounds (in a different order than above).
- *   VAD_MATRIX_BF16X6  as above without the three smallest partial products (<= 2^-23 of a product).
+ *   VAD_MATRIX_BF16X9  (default) every float32 operand is split exactly into three bfloat16 (x = hi + mid + lo)
+ *                      and all nine partial products, each exact in float32, are accumulated in float32 on the
+ *                      bf16 matrix pipe (v_mfma_f32_32x32x16_bf16): no operand or product is rounded, only the
+ *                      accumulation is, as in a float32 FMA chain but in a different order and with the matrix
+ *                      pipe's alignment (error bound and the measurements behind it: DESIGN.md, "bf16x9").
+ *   VAD_MATRIX_F32     v_mfma_f32_32x32x2_f32: a float32 FMA chain in k order, bit-identical to what every other
+ *                      path of this library computes (dense batches, other strides, sampled windows).
+ *   VAD_MATRIX_BF16X6  as BF16X9 without the three smallest partial products (<= 2^-23 of a product).
  * Other strides, sampled windows, wider GRUs and DenseNet always compute as VAD_MATRIX_F32.
  */
 #define VAD_MATRIX_F32 0

@@ -28,3 +28,12 @@ def vad():
     import voice_activity_detection_amd as pkg
     pkg.lib()          # raises if the in-tree libvad_amd.so is missing
     return pkg
+
+
+@pytest.fixture
+def f32_matrix_mode(vad):
+    """The float32-MFMA form of the stride-1 GRU / LSTM kernels for the duration of a test: the mode in which
+    stride-1 windows, dense batches and sampled windows give the same bits."""
+    prev = vad.set_matrix_mode('f32')
+    yield
+    vad.set_matrix_mode(prev)

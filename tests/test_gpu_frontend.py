@@ -188,14 +188,23 @@ def test_full_size_stream_properties(vad):
         _, rm, rd = mfcc_ref.process_test_frames(aligned[3:], aligned[:3])
         assert_feat_close(feat[lo:hi, :12].cpu().numpy(), rm, 'mfcc slice %d' % s)
         assert_feat_close(feat[lo:hi, 12:].cpu().numpy(), rd, 'delta slice %d' % s)
-    # window independence: posteriors of scattered windows from a materialised (B,30,24) batch
+    # window independence: posteriors of scattered windows from a materialised (B,30,24) batch, which the
+    # float32-MFMA kernels compute; the stream's default matrix mode (bf16x9) stays within the bar of them and
+    # of the oracle, and in the float32 matrix mode the whole stream reproduces them bit for bit
     idx = torch.tensor([0, 1, 31, 32, 255, 256, 4_000_000, 7_777_777, n - 31, n - 30], device='cuda')
     batch = torch.stack([feat[i:i + 30] for i in idx.tolist()])
     pb, _ = net.score(batch.contiguous())
-    assert torch.equal(pb, p[idx])
     with torch.no_grad():
         y = ref(batch.cpu()).numpy()
     assert np.abs(pb.cpu().numpy() - y).max() <= 1e-5
+    assert np.abs(p[idx].cpu().numpy() - y).max() <= 1e-5
+    prev = vad.set_matrix_mode('f32')
+    try:
+        p32, _ = net.score(feat, window_stride=24)
+    finally:
+        vad.set_matrix_mode(prev)
+    assert torch.equal(pb, p32[idx])
+    assert float((p32 - p).abs().max()) <= 1e-5                     # all 12 M windows, the two matrix modes
 
 
 def test_gain_and_shift_properties(vad):

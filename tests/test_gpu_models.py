@@ -77,10 +77,32 @@ def test_ragged_batches_match_oracle(vad, kind, batch):
     _decisions_agree(dec.cpu().numpy(), y)
 
 
+@pytest.mark.parametrize('kind', list(NET_KINDS))
+def test_fixture_through_the_stride1_kernels(vad, golden_dir, kind):
+    """The reference-generated fixture through the stride-1 GRU / LSTM kernels in every matrix mode (the default,
+    bf16x9, first): the 64 fixture windows are laid end to end as a (1920,24) feature matrix, whose stride-1
+    windows 0, 30, 60, ... are exactly the fixture windows."""
+    sd, x, y = _fixture(golden_dir, kind)
+    net = _make(vad, kind)
+    net.load_state_dict(sd)
+    feat = torch.from_numpy(x.reshape(-1, 24)).cuda()
+    assert vad.lib().vad_get_matrix_mode() == 2                       # VAD_MATRIX_BF16X9 is the default
+    for mode in ('bf16x9', 'bf16x6', 'f32'):
+        prev = vad.set_matrix_mode(mode)
+        try:
+            p, _ = net.score(feat, window_stride=24)
+        finally:
+            vad.set_matrix_mode(prev)
+        got = p[::30].cpu().numpy()
+        assert got.shape == y.shape
+        assert np.abs(got - y).max() <= ATOL, (mode, np.abs(got - y).max())
+
+
 @pytest.mark.parametrize('kind', ['gru_large', 'lstm_small', 'densenet'])
-def test_sliding_windows_equal_explicit_windows(vad, kind):
+def test_sliding_windows_equal_explicit_windows(vad, kind, f32_matrix_mode):
     """Stride-1 windows read in place from the (F,24) matrix give the same bits as a
-    materialised (B,30,24) batch, and both match the oracle on oracle-made features."""
+    materialised (B,30,24) batch (GRU / LSTM: in the float32-MFMA matrix mode), and both match the
+    oracle on oracle-made features."""
     ref = models_ref.make_model(kind)
     net = _make(vad, kind)
     net.load_state_dict(ref.state_dict())
@@ -97,6 +119,10 @@ def test_sliding_windows_equal_explicit_windows(vad, kind):
     # strided windows (STEP_SIZE = 6, core/train.py:54)
     p6, _ = net.score(fdev, window_stride=24 * 6)
     assert torch.equal(p6, p_slide[::6])
+    # the default matrix mode of the stride-1 kernels (bf16x9) holds the same bar against the oracle
+    vad.set_matrix_mode('bf16x9')
+    p_x9, _ = net.score(fdev, window_stride=24)
+    assert np.abs(p_x9.cpu().numpy() - y).max() <= ATOL
 
 
 @pytest.mark.parametrize('kind', ['gru_large', 'lstm_small'])
@@ -115,7 +141,7 @@ def test_threshold_decisions(vad, kind):
 
 
 @pytest.mark.parametrize('hidden,large', [(90, True), (90, False), (64, True), (33, False), (17, True)])
-def test_gru_other_hidden_sizes(vad, hidden, large):
+def test_gru_other_hidden_sizes(vad, hidden, large, f32_matrix_mode):
     """Enlarged GRU (hidden 90, ~100k parameters): no class in the reference, oracle = torch.nn.GRU + Linear."""
     ref = models_ref.make_model('gru_large' if large else 'gru_small', hidden=hidden)
     net = vad.Net(large=large, lstm=False, hidden=hidden)
@@ -304,14 +330,14 @@ def test_split_bf16_matrix_modes(vad, kind, mode):
     feat_np[200:260] = 0.0
     feat_np[700:705] *= 30.0                                   # outliers: saturated gates
     feat = torch.tensor(feat_np).cuda()
-    p32, d32 = net.score(feat, window_stride=24)
-    prev = vad.set_matrix_mode(mode)
+    prev = vad.set_matrix_mode('f32')
     try:
-        assert prev == 'f32'
+        p32, d32 = net.score(feat, window_stride=24)
+        assert vad.set_matrix_mode(mode) == 'f32'
         p, d = net.score(feat, window_stride=24)
         p_again, _ = net.score(feat, window_stride=24)
     finally:
-        vad.set_matrix_mode('f32')
+        vad.set_matrix_mode(prev)
     assert torch.equal(p, p_again)                              # deterministic
     windows = torch.stack([feat[i:i + 30] for i in range(1471)])
     with torch.no_grad():

@@ -48,7 +48,7 @@ namespace vad {
 using namespace rnn;
 
 // How the stride-1 GRU / LSTM kernels form their float32 matrix products (vad_set_matrix_mode).
-std::atomic<int> g_matrix_mode{VAD_MATRIX_F32};
+std::atomic<int> g_matrix_mode{VAD_MATRIX_BF16X9};
 
 namespace {
 

@@ -24,9 +24,10 @@ MATRIX_MODES = {'f32': 0, 'bf16x6': 1, 'bf16x9': 2}
 
 def set_matrix_mode(mode):
     """Process-wide: how the stride-1 GRU / LSTM kernels form their float32 matrix products.
-    'f32' (default) is the float32 MFMA; 'bf16x9' splits every float32 operand exactly into three bfloat16
-    and accumulates all nine partial products in float32 on the bf16 matrix pipe; 'bf16x6' drops the
-    three smallest partial products.  Returns the previous mode's name."""
+    'bf16x9' (default) splits every float32 operand exactly into three bfloat16 and accumulates all nine exact
+    partial products in float32 on the bf16 matrix pipe; 'f32' is the float32 MFMA (a k-ordered FMA chain,
+    bit-identical to the dense-batch and sampled-window paths); 'bf16x6' drops the three smallest partial
+    products.  Returns the previous mode's name."""
     L = _lib.lib()
     if mode not in MATRIX_MODES:
         raise ValueError('matrix mode must be one of %s' % sorted(MATRIX_MODES))
