@@ -186,7 +186,7 @@ int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t wind
  * the LDS, so unlike the 30-unit models' kernel it cannot keep the projected rows on chip).  Results are
  * bit-identical to vad_gru_forward_f32; other models and strides ignore the workspace.
  *   workspace_dev    caller-owned device memory, 16-byte aligned; any size: the windows are processed in chunks
- *                    of as many as the workspace has rows for (384 floats per row for hidden 65..96, 256 for
+ *                    of as many as the workspace has rows for (288 floats per row for hidden 65..96, 192 for
  *                    33..64; at least 30 rows, else the workspace is not used).  Contents are scratch.
  * vad_gru_workspace_bytes: the size that takes n_windows windows in one chunk (0 where no workspace is used).
  */
