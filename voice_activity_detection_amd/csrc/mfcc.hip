@@ -30,7 +30,7 @@
 // never wait for each other after the block's set-up.
 //
 // Occupancy is the design constraint: a wave stalls on its own LDS exchanges, so the kernel keeps three
-// waves per SIMD (<= 168 VGPRs, 25 KB of LDS per 2-wave block): the input is read straight from global
+// waves per SIMD (<= 168 VGPRs, 48 KB of LDS per 4-wave block): the input is read straight from global
 // memory (no block staging buffer), one of the three twiddle sets lives in a block-shared LDS table.
 //
 // Precision: FFT, power and mel sums in fp32; filter energies, log and DCT in
@@ -50,13 +50,14 @@ using namespace fe;
 
 namespace {
 
-constexpr int kWavesPerBlock = 2;                            // small blocks schedule best (measured 2 < 3 < 4 << 6 waves)
+constexpr int kWavesPerBlock = 4;                            // the block's waves share the twiddle and DCT tables, nothing else
 constexpr int kThreads = 64 * kWavesPerBlock;
 constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twiddle tables
 constexpr int kRingRows = 3 * kFramesPerWave;                // MFCC rows a wave keeps for the delta stencil
 constexpr int kRingBytes = kRingRows * kNCep * 4;
-constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes;
-constexpr int kWavesPerSimd = 3;                             // register budget 168; a block needs 25 KB of LDS
+constexpr int kDctBytes = kDctSteps * 64 * 8;                // block-shared B operands of the DCT matrix product
+constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes;
+constexpr int kWavesPerSimd = 3;                             // register budget 168; three 48 KB blocks per CU
 constexpr int kDeltaReach = 2;                               // delta(feat, 2) looks two rows to either side
 constexpr int kMaxRunFrames = 256;                           // frames one wave computes for one run, halo rows included
 constexpr int kLongRun = kMaxRunFrames - 2 * kDeltaReach;    // owned frames per run of a slice longer than kMaxRunFrames
@@ -74,28 +75,24 @@ struct SliceMap {
 
 // Rows [j_first, j_first + n_emit) of a slice of n frames, from the wave's MFCC ring (row q at slot
 // (q - first) % kRingRows): 12 coefficients and their deltas, d[j] = (-2 f[j-2] - f[j-1] + f[j+1] + 2 f[j+2]) / 10
-// with the slice's own edge rows replicated.  One lane per output float: both halves of a packed 24-float row
-// go out together.
+// with the slice's own edge rows replicated.  One lane per (row, coefficient): it reads the five ring rows of its
+// stencil once and stores the coefficient and its delta (48-byte runs of a packed 24-float row).
 __device__ __forceinline__ void emit_rows(const float* ring, int first, int n, int j_first, int n_emit, int lane,
                                           float* __restrict__ mfcc, long mfcc_ld, float* __restrict__ delta, long delta_ld) {
-    for (int idx = lane; idx < n_emit * 2 * kNCep; idx += 64) {
-        const int r = idx / (2 * kNCep), c2 = idx - r * 2 * kNCep;
+    for (int idx = lane; idx < n_emit * kNCep; idx += 64) {
+        const int r = idx / kNCep, c = idx - r * kNCep;
         const int j = j_first + r;
-        const int c = c2 < kNCep ? c2 : c2 - kNCep;
         auto at = [&](int q) {
             q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
             return ring[((q - first) % kRingRows) * kNCep + c];
         };
-        if (c2 < kNCep) {
-            mfcc[(long)j * mfcc_ld + c] = at(j);
-        } else {
-            const float d = (2.0f * (at(j + 2) - at(j - 2)) + (at(j + 1) - at(j - 1))) / 10.0f;
-            delta[(long)j * delta_ld + c] = d;
-        }
+        const float m2 = at(j - 2), m1 = at(j - 1), f0 = at(j), p1 = at(j + 1), p2 = at(j + 2);
+        mfcc[(long)j * mfcc_ld + c] = f0;
+        delta[(long)j * delta_ld + c] = (2.0f * (p2 - m2) + (p1 - m1)) / 10.0f;
     }
 }
 
-// grid: one wave per run, two waves per block.  Frame j of a slice whose alignment rows start at `rows` reads
+// grid: one wave per run, four waves per block.  Frame j of a slice whose alignment rows start at `rows` reads
 // aligned rows j .. j+3 and their predecessors j-1 .. j+2 (row -1 does not exist: zero_first_pred), and is output
 // row g_lo + j.  Consecutive frames of a wave re-read three of their four rows: those hits are served by the
 // CU's vector L1 / the L2.
@@ -112,6 +109,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
     float* en = reinterpret_cast<float*>(wbase + kExBytes);                  // [4 frames][32]
     float* ring = reinterpret_cast<float*>(wbase + kWaveLdsBytes);           // [kRingRows][12]
     const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
+    const double* dctb = reinterpret_cast<const double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
 
     LaneConst K;
     load_lane_const(K, tab, lane);
@@ -120,6 +118,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
         const float4* src = reinterpret_cast<const float4*>(tab);
         float4* dst = reinterpret_cast<float4*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
         for (int i = threadIdx.x; i < kTwFloat2s / 2; i += kThreads) dst[i] = src[i];
+        const double* dsrc = &tab->dctb[0][0];
+        double* ddst = reinterpret_cast<double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
+        for (int i = threadIdx.x; i < kDctSteps * 64; i += kThreads) ddst[i] = dsrc[i];
         __syncthreads();
     }
 
@@ -170,11 +171,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
                 frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
                 frame_energies(raw, tws, K, ex, en + it * 32, lane);
             }
-            // the table entries a lane reads in the tail do not change from round to round: hide that from the
-            // compiler, which would otherwise keep them in registers across the FFT
-            const MfccTables* tail_tab = tab;
-            asm volatile("" : "+s"(tail_tab));
-            cepstra_tail(en, reinterpret_cast<double*>(wbase), &tail_tab->dctb[0][0], nfr, lane, ring, (fbase - first) % kRingRows, 1,
+            cepstra_tail(en, reinterpret_cast<double*>(wbase), dctb, nfr, lane, ring, (fbase - first) % kRingRows, 1,
                          kRingRows);
             // MFCC rows [first, avail) are in the ring; a row can be written once the rows its delta reads are:
             // everything owned in the last round, otherwise up to two rows behind.

@@ -320,14 +320,8 @@ __device__ __forceinline__ double log_pos(double x) {
 // with C[4 r + (l >> 4)][l & 15] in accumulator element r (layout measured by tools/probes/mfma_f64_layout.hip),
 // so element 0 of lane l is coefficient l & 15 of frame l >> 4.
 // The 12 coefficients of frame `it` go to rows[slot(it) * 12 ..), slot(it) = (slot0 + it * slot_step) % n_slots,
-// a ring of MFCC rows in LDS.  `logv` may alias the exchange region; `dctb` is MfccTables::dctb in global memory.
+// a ring of MFCC rows in LDS.  `logv` may alias the exchange region; `dctb` is the block's LDS copy of MfccTables::dctb.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-
-// A pointer known to point into global memory (plain global_load instead of the generic flat_load, which the
-// compiler falls back to once a pointer has passed through inline assembly).
-__device__ __forceinline__ const __attribute__((address_space(1))) double* global_f64(const double* p) {
-    return (const __attribute__((address_space(1))) double*)p;
-}
 
 __device__ __forceinline__ void cepstra_tail(const float* en, double* logv, const double* __restrict__ dctb, int nfr, int lane,
                                              float* rows, int slot0, int slot_step, int n_slots) {
@@ -344,7 +338,7 @@ __device__ __forceinline__ void cepstra_tail(const float* en, double* logv, cons
         const int i = lane & 15, kk = lane >> 4;
         double b[kDctSteps], a[kDctSteps];
 #pragma unroll
-        for (int s = 0; s < kDctSteps; ++s) b[s] = global_f64(dctb)[s * 64 + lane];
+        for (int s = 0; s < kDctSteps; ++s) b[s] = dctb[s * 64 + lane];
 #pragma unroll
         for (int s = 0; s < kDctSteps; ++s) {
             const int n = 4 * s + kk;
