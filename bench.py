@@ -299,7 +299,6 @@ def main():
     pkg.set_matrix_mode(args.matrix_mode)
     current_mode = [args.matrix_mode]
     prof = load_pmc_profile()
-    free_bytes = torch.cuda.mem_get_info()[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -431,10 +430,31 @@ def main():
         for model in ('lstm_small', 'densenet', 'densenet_large', 'gru_h90'):
             rec, buffers = run_workload(model, args.hours, 3, 1, buffers)
             extra[model] = rec
-        if world == 8 and free_bytes > 200e9:
+        # (BENCH_BIG_WORLD / BENCH_BIG_HOURS rehearse this branch at other sizes)
+        big_hours = float(os.environ.get('BENCH_BIG_HOURS', '1250'))
+        if world == int(os.environ.get('BENCH_BIG_WORLD', '8')):
+            # needs 144 GB of audio + 14 GB of features + 16 GB of workspace per GPU; every rank must take the
+            # same decision, so the ranks agree on it (and on whether their allocations succeeded) first
             buffers = None
-            rec, buffers = run_workload('gru_h90', 1250.0, 2, 1)
-            extra['gru_h90_10000h'] = rec
+            torch.cuda.empty_cache()
+
+            def all_agree(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=red_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return bool(flag.item())
+
+            if all_agree(torch.cuda.mem_get_info()[0] > big_hours * 0.16e9):
+                plan = shard_plan(int(round(big_hours * FRAMES_PER_HOUR)) * world, world, rank, args.slice)
+                try:
+                    stream = pkg.synth_stream(plan['first'], plan['n_load'], seed=1337)
+                    big = ((plan['first'], plan['n_load']), stream, pkg.StreamWorkspace(plan['n_load'], stream.device))
+                    torch.cuda.synchronize()
+                except (RuntimeError, MemoryError):
+                    big = None
+                if all_agree(big is not None):
+                    rec, big = run_workload('gru_h90', big_hours, 2, 1, big)
+                    extra['gru_h90_%dh' % round(big_hours * world)] = rec
+                big = None
         if rank == 0:
             out['configs'] = extra
 
