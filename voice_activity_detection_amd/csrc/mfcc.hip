@@ -56,7 +56,7 @@ constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twi
 constexpr int kRingRows = 3 * kFramesPerWave;                // MFCC rows a wave keeps for the delta stencil
 constexpr int kRingBytes = kRingRows * kNCep * 4;
 constexpr int kDctBytes = kDctSteps * 64 * 8;                // block-shared B operands of the DCT matrix product
-constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes;
+constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes + kPowOffBytes;
 constexpr int kWavesPerSimd = 3;                             // register budget 168; three 48 KB blocks per CU
 constexpr int kDeltaReach = 2;                               // delta(feat, 2) looks two rows to either side
 constexpr int kMaxRunFrames = 256;                           // frames one wave computes for one run, halo rows included
@@ -110,6 +110,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
     float* ring = reinterpret_cast<float*>(wbase + kWaveLdsBytes);           // [kRingRows][12]
     const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
     const double* dctb = reinterpret_cast<const double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
+    const u32x4* pow_off =
+        reinterpret_cast<const u32x4*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes);
+    const int off512 = tab->pow_off_512;
 
     LaneConst K;
     load_lane_const(K, tab, lane);
@@ -121,6 +124,9 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
         const double* dsrc = &tab->dctb[0][0];
         double* ddst = reinterpret_cast<double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
         for (int i = threadIdx.x; i < kDctSteps * 64; i += kThreads) ddst[i] = dsrc[i];
+        const float4* osrc = reinterpret_cast<const float4*>(&tab->pow_off[0][0][0]);
+        float4* odst = reinterpret_cast<float4*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes);
+        for (int i = threadIdx.x; i < kPowOffBytes / 16; i += kThreads) odst[i] = osrc[i];
         __syncthreads();
     }
 
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
                 // 30 live registers and the third wave per SIMD already covers the load latency)
                 RawFrame raw;
                 frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
-                frame_energies(raw, tws, K, ex, en + it * 32, lane);
+                frame_energies(raw, tws, pow_off, off512, K, ex, en + it * 32, lane);
             }
             cepstra_tail(en, reinterpret_cast<double*>(wbase), dctb, nfr, lane, ring, (fbase - first) % kRingRows, 1,
                          kRingRows);
@@ -240,6 +246,22 @@ void build_tables(MfccTables& t) {
             t.run_b1[lane] = edge[s + 1];
             t.run_inv[lane] = (float)(1.0 / (double)len);
         }
+    }
+    // where the FFT lanes put their bins: bin k of run-lane L sits at float kRunSlot * L + (k - run_start[L]);
+    // bin 1024 belongs to no filter and goes to the last float of the (idle) last lane's slot
+    {
+        int slot_of[1025];
+        for (int k = 0; k <= 1024; ++k) slot_of[k] = kRunSlot * 63 + kRunSlot - 1;
+        for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < t.run_count[l]; ++i) slot_of[t.run_start[l] + i] = kRunSlot * l + i;
+        if (t.run_count[63] == kRunSlot) abort();
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int k = (l >> 4) + 4 * (l & 15) + 64 * j;
+                t.pow_off[0][l][j] = (unsigned short)(4 * slot_of[k]);
+                t.pow_off[1][l][j] = (unsigned short)(4 * slot_of[1024 - k]);
+            }
+        t.pow_off_512 = 4 * slot_of[512];
     }
     for (int f = 0; f < kNFilt; ++f) {
         t.rise_first[f] = seg_first[f];

@@ -1,6 +1,7 @@
 // Device-side building blocks of the MFCC front end (kernel and launch code: mfcc.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "vad_internal.h"
@@ -19,7 +20,9 @@ constexpr int kEx1Stride = 272;               // exchange 1: complex elements pe
 constexpr int kEx2Plane = 272;                // exchange 2: complex elements per k1 plane (16 rows of 17): the two
                                               // planes of a 32-lane half interleave on the 64 banks
 constexpr int kExBytes = 8704;                // = 4*272*8 >= (3*272 + 15*17 + 16)*8, >= 1024*8
-constexpr int kPowFloats = 1056;              // P[0..1024] plus slack for reads past a lane's run (kept inside the region)
+constexpr int kRunSlot = 20;                  // power spectrum in LDS: the run of mel lane l occupies floats [20 l, 20 l + 20),
+                                              // so the lanes' 16-byte reads of their runs fall on distinct banks
+constexpr int kPowFloats = 64 * kRunSlot;
 
 struct MfccTables {
     float2 tw1[12][64];      // [(k1-1)*4 + b][lane]  W1024^((lane + 64 b) * k1)
@@ -37,7 +40,13 @@ struct MfccTables {
     double dct[kNFilt][kNCep];   // sqrt(2/26) * lifter(k) * cos(pi k (2n+1) / 52), k = 1..12
     double dctb[kDctSteps][64];  // the same matrix as B operands of v_mfma_f64_16x16x4_f64: step s, lane l holds
                                  // dct[4 s + (l >> 4)][l & 15], zero outside 26 x 12
+    unsigned short pow_off[2][64][8];   // byte offset, inside the power-spectrum image, of the bins FFT lane l produces:
+                                        // [0][l][jj] bin k = (l >> 4) + 4 (l & 15) + 64 jj, [1][l][jj] bin 1024 - k
+    int pow_off_512;                    // the same for bin 512 (lane 0's self-paired bin)
 };
+
+static_assert(offsetof(MfccTables, pow_off) % 16 == 0 && offsetof(MfccTables, dctb) % 8 == 0,
+              "tables that are copied to LDS in 16-byte pieces");
 
 // ---------------------------------------------------------------------------------------------
 // device helpers
@@ -107,12 +116,13 @@ static_assert((kPartOffset + 128) * 4 <= kExBytes, "power spectrum + partial sum
 // Block-shared LDS image of the W1024 twiddles tw1[12][64] (the head of MfccTables); the other two sets
 // live in registers.
 constexpr int kTwFloat2s = 12 * 64;
+constexpr int kPowOffBytes = 2 * 64 * 8 * 2;   // block-shared LDS image of MfccTables::pow_off
 
 // Loop-invariant per-lane constants that stay in registers (the twiddles do not: see frame_energies).
 struct LaneConst {
     float2 tw2[15];                           // W256^(c q1) of this lane's c  } the twiddle sets that fit the
     float2 twr[8];                            // W2048^(k1 + 4 q1 + 64 jj)       } registers at 3 waves per SIMD
-    int run_start, run_count;
+    int run_count;
     float run_inv, run_w0, run_f0;
     int rise_first, rise_n, fall_first, fall_n;
     int k1l, q1l, plane, kbase;
@@ -123,12 +133,12 @@ __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* 
     for (int k = 0; k < 15; ++k) K.tw2[k] = tab->tw2[k][lane & 15];
 #pragma unroll
     for (int j = 0; j < 8; ++j) K.twr[j] = tab->twr[j][lane];
-    K.run_start = tab->run_start[lane];
+    const int run_start = tab->run_start[lane];
     K.run_count = tab->run_count[lane];
     const float b0 = (float)tab->run_b0[lane], b1 = (float)tab->run_b1[lane];
     K.run_inv = tab->run_inv[lane];
-    K.run_w0 = ((float)K.run_start - b0) * K.run_inv;      // rising weight of the run's first bin
-    K.run_f0 = (b1 - (float)K.run_start) * K.run_inv;      // falling weight of the run's first bin
+    K.run_w0 = ((float)run_start - b0) * K.run_inv;        // rising weight of the run's first bin
+    K.run_f0 = (b1 - (float)run_start) * K.run_inv;        // falling weight of the run's first bin
     const int fl = lane < kNFilt ? lane : 0;
     K.rise_first = tab->rise_first[fl];
     K.rise_n = tab->rise_n[fl];
@@ -166,8 +176,12 @@ __device__ __forceinline__ void frame_load(RawFrame& raw, const int* __restrict_
 // instead of living in ~70 registers: the kernel is latency-bound (in-order waves stalling on their own
 // LDS exchanges), three waves per SIMD need the register file, and reading them from global memory
 // instead makes the kernel texture-path-bound (measured 2.2x slower).
-__device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, const LaneConst& K, float2* ex,
-                                               float* en_slot, int lane) {
+// `pow_off` is the block's LDS copy of MfccTables::pow_off, `off512` MfccTables::pow_off_512.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, const u32x4* pow_off, int off512,
+                                               const LaneConst& K, float2* ex, float* en_slot, int lane) {
     float* pw = reinterpret_cast<float*>(ex);                               // aliases ex once exchange 2 is read
     float* part_r = pw + kPartOffset;
     float* part_f = part_r + 64;
@@ -230,6 +244,8 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     //      Z[1024 - k] is register 15 - jj of lane `plane` (a cross-lane read, no LDS image of Z);
     //      lane 0 holds the bins 64 q2, whose partners 64 (16 - q2) are its own registers. ----
     const int paddr = K.plane * 4;
+    const u32x4 off_lo = pow_off[lane], off_hi = pow_off[64 + lane];       // 8 + 8 packed 16-bit byte offsets
+    unsigned char* pwb = reinterpret_cast<unsigned char*>(pw);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         const float2 a = v[jj];
@@ -242,21 +258,27 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         const float2 t = cmul(K.twr[jj], o);
         const float ar = e.x + t.y, ai = e.y - t.x;                       // E - iT
         const float br = e.x - t.y, bi = e.y + t.x;                       // E + iT
-        const int k = K.kbase + 64 * jj;
-        pw[k] = (ar * ar + ai * ai) * (0.25f / 2048.0f);
-        pw[1024 - k] = (br * br + bi * bi) * (0.25f / 2048.0f);
+        const unsigned wl = off_lo[jj >> 1], wh = off_hi[jj >> 1];
+        const unsigned o_lo = (jj & 1) ? wl >> 16 : wl & 0xFFFFu, o_hi = (jj & 1) ? wh >> 16 : wh & 0xFFFFu;
+        *reinterpret_cast<float*>(pwb + o_lo) = (ar * ar + ai * ai) * (0.25f / 2048.0f);      // bin k
+        *reinterpret_cast<float*>(pwb + o_hi) = (br * br + bi * bi) * (0.25f / 2048.0f);      // bin 1024 - k
     }
-    if (lane == 0) pw[512] = (v[8].x * v[8].x + v[8].y * v[8].y) * (1.0f / 2048.0f);   // the self-paired bin
+    if (lane == 0)                                                                             // the self-paired bin 512
+        *reinterpret_cast<float*>(pwb + off512) = (v[8].x * v[8].x + v[8].y * v[8].y) * (1.0f / 2048.0f);
     wave_lds_fence();
 
-    // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the
-    // 20 reads issue back to back, lanes past their run add zeros) ----
+    // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the lane reads
+    // its whole 20-float slot in five 16-byte reads, elements past its run count as zeros) ----
     {
         float sr = 0.0f, sf = 0.0f;
-        const float* run = pw + K.run_start;
+        static_assert(kMaxRun == kRunSlot && kRunSlot % 4 == 0, "a run is read as whole 16-byte pieces of its slot");
+        const f32x4v* run4 = reinterpret_cast<const f32x4v*>(pw + kRunSlot * lane);
+        f32x4v piece[kRunSlot / 4];
+#pragma unroll
+        for (int q = 0; q < kRunSlot / 4; ++q) piece[q] = run4[q];
 #pragma unroll
         for (int i = 0; i < kMaxRun; ++i) {
-            const float p = (i < K.run_count) ? run[i] : 0.0f;
+            const float p = (i < K.run_count) ? piece[i >> 2][i & 3] : 0.0f;
             sr = fmaf(p, fmaf((float)i, K.run_inv, K.run_w0), sr);
             sf = fmaf(p, fmaf(-(float)i, K.run_inv, K.run_f0), sf);
         }
