@@ -57,7 +57,7 @@ struct DnLayout {
 };
 
 // Offset of growth layer i inside its dense block: layers 0..i-1 hold (c0 + g k) * 12 + 4 floats each.
-__host__ __device__ inline int dense_layer_offset(int c0, int g, int i) {
+__host__ __device__ constexpr int dense_layer_offset(int c0, int g, int i) {
     return i * (c0 * 12 + 4) + 6 * g * i * (i - 1);
 }
 
@@ -89,6 +89,14 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// x of this lane + x of the lane 32 away, in every lane: v_permlane32_swap exchanges the upper half of one
+// register with the lower half of another in the vector ALU (ds_bpermute would go through the LDS pipe).
+__device__ __forceinline__ float sum_across_halves(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = lower half twice, r[1] = upper half twice
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ f32x16 load_shift(const float* p, int half) {
     const float4* s = reinterpret_cast<const float4*>(p + half * 16);
     f32x16 r;
@@ -117,7 +125,7 @@ struct ActView {
 
 // One dense block: NL growth layers over L positions, appended channel by channel.
 template <int NL, int G, int L>
-__device__ __forceinline__ void dense_block(const ActView& v, const float* __restrict__ block_w, int c_first, int half) {
+__device__ __forceinline__ void dense_block(const ActView& v, const float* block_w, int c_first, int half) {
 #pragma unroll
     for (int layer = 0; layer < NL; ++layer) {                    // unrolled: the channel count below is a constant
         const int cin = c_first + G * layer;
@@ -158,7 +166,7 @@ __device__ __forceinline__ void dense_block(const ActView& v, const float* __res
         for (int o = 0; o < G; ++o)
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                const float y = lrelu(acc[o][l] + __shfl_xor(acc[o][l], 32, 64) + sh[o]);
+                const float y = lrelu(sum_across_halves(acc[o][l]) + sh[o]);
                 if (half == 0) v.b[(cin + o - c_first) * v.b_c + l * v.b_l] = y;
             }
         wave_lds_fence();
@@ -201,8 +209,10 @@ __device__ __forceinline__ void stem_pair(const float* xe_row, const float* __re
 
 // Everything after the stem for a wave's 32 windows: dense block 1 over `v1`, transition into the plain
 // private array act2[c][2][32] (which may alias v1's growth region), dense block 2, cnn_out, Linear, softmax.
+// `dense_w[b]` points at the growth-layer weights of dense block b (the blob's, or a copy in LDS).
 template <bool LARGE>
 __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, const float* __restrict__ blob,
+                                              const float* dense_w0, const float* dense_w1,
                                               const DnLayout& LY, int lane, long w, long n_windows,
                                               float* __restrict__ p_out, uint8_t* __restrict__ dec_out, int mode,
                                               float threshold) {
@@ -210,7 +220,7 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
     const int half = lane >> 5, col = lane & 31;
 
     // ---- dense block 1 (5 positions) ----
-    dense_block<D::nl, D::g, kL1>(v1, blob + LY.dense[0], D::c0, half);
+    dense_block<D::nl, D::g, kL1>(v1, dense_w0, D::c0, half);
 
     // ---- transition: 1x1 conv c1 -> c0 + BN + MaxPool(2) + LeakyReLU, 5 -> 2 (position 4 is dropped) ----
     f32x16 tr[D::mt0][kL2];
@@ -250,7 +260,7 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
 
     // ---- dense block 2 (2 positions) ----
     const ActView v2{act2 + col, kL2 * 32, 32, act2 + D::c0 * kL2 * 32 + col, kL2 * 32, 32, D::c0};
-    dense_block<D::nl, D::g, kL2>(v2, blob + LY.dense[1], D::c0, half);
+    dense_block<D::nl, D::g, kL2>(v2, dense_w1, D::c0, half);
 
     // ---- cnn_out: 1x1 conv c1 -> c1 + BN + MaxPool(2) + LeakyReLU, 2 -> 1; then Linear(c1 -> 2) ----
     float l0 = 0.0f, l1 = 0.0f;
@@ -274,8 +284,8 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
             l1 = fmaf(y, wf1[i], l1);
         }
     }
-    l0 += __shfl_xor(l0, 32, 64);
-    l1 += __shfl_xor(l1, 32, 64);
+    l0 = sum_across_halves(l0);
+    l1 = sum_across_halves(l1);
     const float m = fmaxf(l0, l1);
     const float e0 = expf(l0 - m), e1 = expf(l1 - m);
     const float inv = 1.0f / (e0 + e1);
@@ -310,7 +320,8 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
     wave_lds_fence();
 
     const ActView v1{act + col, kL1 * 32, 32, act + D::c0 * kL1 * 32 + col, kL1 * 32, 32, D::c0};
-    densenet_tail<LARGE>(v1, act, blob, LY, lane, w, n_windows, p_out, dec_out, mode, threshold);
+    densenet_tail<LARGE>(v1, act, blob, blob + LY.dense[0], blob + LY.dense[1], LY, lane, w, n_windows, p_out, dec_out,
+                         mode, threshold);
 }
 
 // Stride-1 windows over a packed (F, 24) matrix.  The stem output at pooled position lp of window w is
@@ -327,7 +338,11 @@ struct DnStreamCfg {
     static constexpr int grow = D::nl * D::g;                    // growth channels of a dense block
     static constexpr int priv1 = grow * kL1 * 32, priv2 = D::c1 * kL2 * 32;
     static constexpr int priv = priv1 > priv2 ? priv1 : priv2;   // per wave: block-1 growth channels, then all of block 2
-    static constexpr int lds_floats = D::c0 * rows + waves * priv;
+    // The growth-layer weights of both dense blocks are read once per channel by every wave, two addresses
+    // per wave-instruction: the small model keeps a block-shared copy in LDS (the large model's LDS is full).
+    static constexpr bool dense_in_lds = !LARGE;
+    static constexpr int dense_floats = dense_in_lds ? 2 * dense_layer_offset(D::c0, D::g, D::nl) : 0;
+    static constexpr int lds_floats = D::c0 * rows + waves * priv + dense_floats;
 };
 
 template <bool LARGE>
@@ -344,6 +359,12 @@ __global__ __launch_bounds__(DnStreamCfg<LARGE>::waves * 64) void densenet_strea
     const int col = lane & 31;
     const int wave = threadIdx.x >> 6;
     float* priv = lds + D::c0 * C::rows + wave * C::priv;
+    float* dense_lds = lds + D::c0 * C::rows + C::waves * C::priv;
+    if (C::dense_in_lds) {                                       // visible after the barrier that ends phase 1
+        const float4* src = reinterpret_cast<const float4*>(blob + LY.dense[0]);
+        float4* dst = reinterpret_cast<float4*>(dense_lds);
+        for (int i = threadIdx.x; i < C::dense_floats / 4; i += C::waves * 64) dst[i] = src[i];
+    }
     const long w0 = (long)blockIdx.x * C::windows;
     const long last_row = n_windows + VAD_FRAMES - 2;            // the matrix has n_windows + 29 rows
 
@@ -366,7 +387,9 @@ __global__ __launch_bounds__(DnStreamCfg<LARGE>::waves * 64) void densenet_strea
     if (w0 + wave * 32 >= n_windows) return;                     // wave-uniform, after the only barrier
     const int ml = owned ? wl : C::windows - 1;                  // keep M reads inside the image
     const ActView v1{M + ml, C::rows, 2, priv + col, kL1 * 32, 32, D::c0};
-    densenet_tail<LARGE>(v1, priv, blob, LY, lane, w, n_windows, p_out, dec_out, mode, threshold);
+    const float* dw0 = C::dense_in_lds ? dense_lds : blob + LY.dense[0];
+    const float* dw1 = C::dense_in_lds ? dense_lds + dense_layer_offset(D::c0, D::g, D::nl) : blob + LY.dense[1];
+    densenet_tail<LARGE>(v1, priv, blob, dw0, dw1, LY, lane, w, n_windows, p_out, dec_out, mode, threshold);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -175,16 +175,17 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
                 // 30 live registers and the third wave per SIMD already covers the load latency)
                 RawFrame raw;
                 frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
-                frame_energies(raw, tws, pow_off, off512, K, ex, en + it * 32, lane);
+                frame_energies(raw, tws, pow_off, off512, K, ex, en + it * 32);
             }
-            cepstra_tail(en, reinterpret_cast<double*>(wbase), dctb, nfr, lane, ring, (fbase - first) % kRingRows, 1,
-                         kRingRows);
+            const int tl = fresh_lane();                                    // see fresh_lane: nothing of the tail's
+            cepstra_tail(en, reinterpret_cast<double*>(wbase), dctb, nfr, tl, ring, (fbase - first) % kRingRows, 1,
+                         kRingRows);                                        // addressing stays live over the frames
             // MFCC rows [first, avail) are in the ring; a row can be written once the rows its delta reads are:
             // everything owned in the last round, otherwise up to two rows behind.
             const int avail = last - fbase > kFramesPerWave ? fbase + kFramesPerWave : last;
             const int upto = avail == last ? own_hi : (avail - kDeltaReach < own_hi ? avail - kDeltaReach : own_hi);
             const int n_emit = upto > emitted ? upto - emitted : 0;
-            emit_rows(ring, first, n, emitted, n_emit, lane, mfcc, mfcc_ld, delta, delta_ld);
+            emit_rows(ring, first, n, emitted, n_emit, tl, mfcc, mfcc_ld, delta, delta_ld);
             emitted += n_emit;
             wave_lds_fence();                                               // ring reads before the next round's writes
         }

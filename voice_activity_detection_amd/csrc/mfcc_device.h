@@ -98,6 +98,15 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
         }
 }
 
+// The lane index, recomputed where it is called.  Addresses derived from a lane index that the compiler can
+// see is loop-invariant are hoisted to kernel entry and kept in vector registers across the whole frame loop
+// (or spilled around it); two instructions per use are cheaper than those registers.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // LDS traffic below is between lanes of ONE wave.  LDS operations of a wave
 // complete in issue order, so only the compiler has to be kept from moving
 // loads above the stores of other lanes.
@@ -125,7 +134,6 @@ struct LaneConst {
     int run_count;
     float run_inv, run_w0, run_f0;
     int rise_first, rise_n, fall_first, fall_n;
-    int k1l, q1l, plane, kbase;
 };
 
 __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* __restrict__ tab, int lane) {
@@ -144,11 +152,6 @@ __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* 
     K.rise_n = tab->rise_n[fl];
     K.fall_first = tab->fall_first[fl];
     K.fall_n = tab->fall_n[fl];
-    // untangle partner of bin k = k1 + 4 q1 + 64 jj: register 15 - jj of lane `plane` (lane 0 pairs with itself)
-    K.k1l = lane >> 4;
-    K.q1l = lane & 15;
-    K.plane = K.k1l ? 16 * (4 - K.k1l) + 15 - K.q1l : (K.q1l ? 16 - K.q1l : 0);
-    K.kbase = K.k1l + 4 * K.q1l;
 }
 
 // Raw input of one frame as this lane holds it: int16 pairs n = lane + 64 jj of the frame's four rows
@@ -181,7 +184,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, const u32x4* pow_off, int off512,
-                                               const LaneConst& K, float2* ex, float* en_slot, int lane) {
+                                               const LaneConst& K, float2* ex, float* en_slot) {
+    const int lane = fresh_lane();
+    const int k1l = lane >> 4, q1l = lane & 15;
     float* pw = reinterpret_cast<float*>(ex);                               // aliases ex once exchange 2 is read
     float* part_r = pw + kPartOffset;
     float* part_f = part_r + 64;
@@ -210,7 +215,7 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         for (int b = 0; b < 4; ++b) ex[k1 * kEx1Stride + lane + 64 * b] = v[4 * k1 + b];
     wave_lds_fence();
     {
-        const float2* rd = ex + K.k1l * kEx1Stride + K.q1l;
+        const float2* rd = ex + k1l * kEx1Stride + q1l;
 #pragma unroll
         for (int m = 0; m < 16; ++m) v[m] = rd[16 * m];
     }
@@ -223,13 +228,13 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
 
     // ---- exchange 2: [k1][q1][c] -> lane (k1, q1) reads c = 0..15 ----
     {
-        float2* wr = ex + K.k1l * kEx2Plane + K.q1l;
+        float2* wr = ex + k1l * kEx2Plane + q1l;
 #pragma unroll
         for (int q = 0; q < 16; ++q) wr[17 * q] = v[q];
     }
     wave_lds_fence();
     {
-        const float2* rd = ex + K.k1l * kEx2Plane + 17 * K.q1l;
+        const float2* rd = ex + k1l * kEx2Plane + 17 * q1l;
 #pragma unroll
         for (int c = 0; c < 16; ++c) v[c] = rd[c];
     }
@@ -243,7 +248,8 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     //      4 |X[k]|^2 = |E - iT|^2 and 4 |X[N-k]|^2 = |E + iT|^2.
     //      Z[1024 - k] is register 15 - jj of lane `plane` (a cross-lane read, no LDS image of Z);
     //      lane 0 holds the bins 64 q2, whose partners 64 (16 - q2) are its own registers. ----
-    const int paddr = K.plane * 4;
+    const int plane = k1l ? 16 * (4 - k1l) + 15 - q1l : (q1l ? 16 - q1l : 0);
+    const int paddr = plane * 4;
     const u32x4 off_lo = pow_off[lane], off_hi = pow_off[64 + lane];       // 8 + 8 packed 16-bit byte offsets
     unsigned char* pwb = reinterpret_cast<unsigned char*>(pw);
 #pragma unroll
