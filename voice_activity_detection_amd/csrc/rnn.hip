@@ -213,9 +213,17 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
 // The input projection (1/30 of the matrix work) stays on the float32 MFMA.
 
 template <bool LSTM>
-struct SplitCfg : StreamGeom<LSTM, LSTM ? 7 : 8> {
-    using B = StreamGeom<LSTM, LSTM ? 7 : 8>;
-    static constexpr int lds_floats = B::gi_floats + B::G * kSplitTile + 4 * 2 * 16;
+struct SplitCfg {
+    static constexpr int G = LSTM ? 4 : 3;
+    static constexpr int waves = LSTM ? 7 : 8;
+    static constexpr int windows = waves * kWindowsPerWave;
+    static constexpr int tiles = waves + 1;
+    // Row stride of the projections in floats.  A 16-byte read of the steps takes rows n = 0..15 from lanes with
+    // q = 0 or 1 (4 floats apart): with rs / 4 = 2 (mod 16) the sixteen lanes of a read group fall on distinct
+    // banks (GRU, 104).  The LSTM's LDS has no room for the next such stride (136): 132 leaves one 2-way pair.
+    static constexpr int rs = LSTM ? 132 : 104;
+    static constexpr int gi_floats = tiles * 32 * rs;
+    static constexpr int lds_floats = gi_floats + G * kSplitTile + 4 * 2 * 16;
 };
 
 template <bool LSTM, bool LARGE, int TERMS>
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
     const long w0 = (long)blockIdx.x * C::windows;
     const long last_row = n_windows + kT - 2;
 
-    // ---- phase 1: gi[row][gate * 32 + unit] = bias + W_ih x_row (float32 MFMA, as rnn_stream_kernel) ----
+    // ---- phase 1: gi[row][gate * 32 + tile row] = bias + W_ih x_row (float32 MFMA, as rnn_stream_kernel) ----
     for (int task = wave; task < C::tiles * G; task += C::waves) {
         const int tile = task / G, g = task - tile * G;
         long row = w0 + tile * 32 + col;
@@ -258,38 +266,48 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
     }
     __syncthreads();
 
-    // ---- phase 2: 30 steps for the wave's 32 windows.  A wave alternates between a matrix phase (18 or 27
-    // bf16 MFMAs per tile) and a vector phase (gate math, bf16 split); the two waves that share a SIMD
-    // (w and w + 4) overlap only while they are in different phases, and left alone they start in lockstep,
-    // so the second one is delayed once by about half a step. ----
-    const long w = w0 + wave * kWindowsPerWave + col;
+    // ---- phase 2: 30 steps for the wave's 32 windows, in the 16 x 16 sub-tile layout (rnn_device.h): lane
+    // 16 q + n holds tile rows 16 mi + 4 q + i of windows n and 16 + n.  A wave alternates between a matrix phase
+    // (24 or 36 bf16 MFMAs of 16 cycles per tile) and a vector phase (gate math, bf16 split); the two waves that
+    // share a SIMD (w and w + 4) overlap while they are in different phases. ----
     if (w0 + wave * kWindowsPerWave >= n_windows) return;       // wave-uniform, after the only barrier
+    const int q = lane >> 4, n = lane & 15;
+    const long w_first = w0 + wave * kWindowsPerWave + n;        // the lane's windows: w_first and w_first + 16
     const float* a1 = blob + L.head;
     const u32x4* s_gate = reinterpret_cast<const u32x4*>(s_hh);
     const u32x4* s_head = reinterpret_cast<const u32x4*>(blob + L.s_head);
     f32x16 h, c, lacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { h[i] = 0.0f; c[i] = 0.0f; lacc[i] = 0.0f; }
-    const float* girow = gi + (wave * kWindowsPerWave + col) * C::rs + 4 * half;
+    const float* girow = gi + (wave * kWindowsPerWave + n) * C::rs + 4 * q;
+    const float* cb_n = cb + (3 * 2 + split_image_half(q)) * 16;             // b_hn of the lane's rows
     SplitB b;
-#ifndef VAD_SPLIT_STAGGER
-#define VAD_SPLIT_STAGGER 14
-#endif
-    if ((wave >> 2) != 0 && VAD_SPLIT_STAGGER > 0) __builtin_amdgcn_s_sleep(VAD_SPLIT_STAGGER);   // x 64 cycles
 
     for (int t = 0; t < kT; ++t) {
-        HeadWeights<false, kHk> hw;                              // 2-row head: vector ALU, float32 weights
-        if (!LARGE) head_load<false, kHk>(hw, a1, t, lane);
+        SplitHeadWeights hw;                                     // 2-row head: vector ALU, float32 weights
+        if (!LARGE) split_head_load(hw, a1, t, lane);
         f32x16 acc[4];
-        const float* src = girow + t * C::rs;
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(src + g * 32 + 8 * q);
-                acc[g][4 * q] = v.x; acc[g][4 * q + 1] = v.y; acc[g][4 * q + 2] = v.z; acc[g][4 * q + 3] = v.w;
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float4 v = *reinterpret_cast<const float4*>(girow + (16 * ni + t) * C::rs + g * 32 + 16 * mi);
+                    acc[g][split_index(mi, ni, 0)] = v.x; acc[g][split_index(mi, ni, 1)] = v.y;
+                    acc[g][split_index(mi, ni, 2)] = v.z; acc[g][split_index(mi, ni, 3)] = v.w;
+                }
+        if (!LSTM) {                                             // b_hn
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const float4 v = *reinterpret_cast<const float4*>(cb_n + split_image_elem(q, mi));
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[3][split_index(mi, ni, 0)] = v.x; acc[3][split_index(mi, ni, 1)] = v.y;
+                    acc[3][split_index(mi, ni, 2)] = v.z; acc[3][split_index(mi, ni, 3)] = v.w;
+                }
             }
-        if (!LSTM) acc[3] = load16(cb + (3 * 2 + half) * 16);    // b_hn
+        }
         if (t > 0) {                                             // b holds the split of h_{t-1}
             if (LARGE) lacc = split_tile_mfma<TERMS>(lacc, s_head + (t - 1) * (kSplitTile / 4), b, lane);
             if (LSTM) {
@@ -303,11 +321,10 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
         }
         gate_update<LSTM>(acc, h, c);
         split_state(b, h);                                       // for this step's head and the next step's gates
-        if (!LARGE) head_step<false, kHk>(lacc, hw, h);
+        if (!LARGE) split_head_step(lacc, hw, h);
     }
     if (LARGE) lacc = split_tile_mfma<TERMS>(lacc, s_head + (kT - 1) * (kSplitTile / 4), b, lane);
-    head_finish<LARGE>(lacc);
-    head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
+    split_head_epilogue<LARGE>(lacc, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -876,14 +893,16 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
         tail[1] = lin_b[1];
     }
     if (UT == 1) {
-        // bf16 (hi, mid, lo) images of the float32 A operands above: element j of k-step s (of 16) is the
-        // float32 k-step 8 s + j of the same lane
+        // bf16 (hi, mid, lo) images of the float32 A operands above as v_mfma_f32_16x16x32_bf16 A operands: sub-tile
+        // mi, lane l = 16 q + m holds tile row 16 mi + m, k-slots 8 q + j = tile rows split_row_of_k_slot(q, j); in the
+        // float32 image tile row p is k-step (p & 3) + 4 (p >> 3) of lane half (p >> 2) & 1
         auto split_tile = [&](const float* a16, float* dst) {      // a16: [16][64] floats -> [2][3][64][8 bf16]
             uint16_t* out = reinterpret_cast<uint16_t*>(dst);
-            for (int s = 0; s < 2; ++s)
+            for (int mi = 0; mi < 2; ++mi)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const float x = a16[(8 * s + j) * 64 + lane];
+                        const int m = 16 * mi + (lane & 15), p = split_row_of_k_slot(lane >> 4, j);
+                        const float x = a16[((p & 3) + 4 * (p >> 3)) * 64 + m + 32 * ((p >> 2) & 1)];
                         uint32_t bits;
                         memcpy(&bits, &x, 4);
                         const uint32_t hb = bits & 0xFFFF0000u;
@@ -896,9 +915,9 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
                         memcpy(&mid, &mb, 4);
                         const float r2 = r1 - mid;
                         memcpy(&bits, &r2, 4);
-                        out[(((s * 3 + 0) * 64 + lane) * 8) + j] = (uint16_t)(hb >> 16);
-                        out[(((s * 3 + 1) * 64 + lane) * 8) + j] = (uint16_t)(mb >> 16);
-                        out[(((s * 3 + 2) * 64 + lane) * 8) + j] = (uint16_t)(bits >> 16);
+                        out[(((mi * 3 + 0) * 64 + lane) * 8) + j] = (uint16_t)(hb >> 16);
+                        out[(((mi * 3 + 1) * 64 + lane) * 8) + j] = (uint16_t)(mb >> 16);
+                        out[(((mi * 3 + 2) * 64 + lane) * 8) + j] = (uint16_t)(bits >> 16);
                     }
         };
         for (int g = 0; g < G; ++g) split_tile(blob + L.a_hh + g * kHk * 64, blob + L.s_hh + g * kSplitTile);

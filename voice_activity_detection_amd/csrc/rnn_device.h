@@ -34,7 +34,7 @@ struct NetLayout {
     int total;
 };
 
-constexpr int kSplitTile = 2 * 3 * 64 * 4;   // dwords of one split 32x32 A tile: 2 k-steps of 16, 3 terms, 16 B per lane
+constexpr int kSplitTile = 2 * 3 * 64 * 4;   // dwords of one split 32x32 A tile: 2 halves of 16 rows, 3 terms, 16 B per lane
 
 __host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 1) {
     NetLayout L;
@@ -93,57 +93,85 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // ---- fp32 products on the bf16 matrix pipe ---------------------------------------------------------
 // A float32 is the exact sum of three bfloat16 (8 + 8 + 8 significant bits, by truncation: hi = the upper
 // 16 bits, mid = the upper 16 bits of x - hi, lo = x - hi - mid).  x * y is then the exact sum of the nine
-// bf16 x bf16 partial products, each of which v_mfma_f32_32x32x16_bf16 forms exactly and adds in float32.
+// bf16 x bf16 partial products, each of which the bf16 MFMA forms exactly and adds in float32.
 // With all 9 terms the only rounding left is the float32 accumulation, as in a float32 FMA chain; with 6
-// terms the three smallest (mid*lo, lo*mid, lo*lo, <= 2^-23 of the product) are dropped.  A bf16 MFMA
-// costs 32 cycles for K = 16 against 8 x 64 cycles for the same K on the float32 MFMA, and unlike the
+// terms the three smallest (mid*lo, lo*mid, lo*lo, <= 2^-23 of the product) are dropped.  The bf16 matrix
+// pipe does K = 32 of a 32 x 32 tile in 64 cycles against 16 x 64 cycles on the float32 MFMA, and unlike the
 // float32 MFMA it runs beside vector instructions.
+//
+// The instruction is v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it than on the 32x32x16
+// shape): a wave's 32 units x 32 windows are four 16 x 16 sub-tiles (mi, ni) = (unit half, window half), and the
+// whole K = 32 of the hidden state is one instruction.  Lane l = 16 q + n holds, of sub-tile (mi, ni), tile rows
+// 16 mi + 4 q + i (i = 0..3) of window 16 ni + n in accumulator element i: element (mi, ni, i) of a tile is
+// index (2 mi + ni) * 4 + i of an f32x16.  As B operand the same lane supplies k-slots 8 q + j (j = 0..7) of
+// window 16 ni + n; with k-slot 8 q + j := tile row 16 (j >> 2) + 4 q + (j & 3) those are exactly the eight rows
+// the lane holds for that window, so the hidden state never leaves its lane, and the A operands carry their
+// columns in that k-slot order.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 #define MFMA_BF16(a, b, c) \
-    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+    __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-// B operands (hi, mid, lo) of the lane's registers 8 s .. 8 s + 7, s = 0, 1: element j of k-step s is register 8 s + j
+__host__ __device__ inline int split_index(int mi, int ni, int i) { return (2 * mi + ni) * 4 + i; }
+__host__ __device__ inline int split_row_of_k_slot(int q, int j) { return 16 * (j >> 2) + 4 * q + (j & 3); }
+
+// B operands (hi, mid, lo) of the lane's two windows: [ni], dword jp = k-slots 2 jp (low half) and 2 jp + 1
 struct SplitB {
     u32x4 hi[2], mid[2], lo[2];
 };
 
 __device__ __forceinline__ void split_state(SplitB& b, const f32x16& h) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-            const float x0 = h[8 * s + 2 * jp], x1 = h[8 * s + 2 * jp + 1];
+            const int j = 2 * jp;                                       // j and j + 1 share j >> 2
+            const float x0 = h[split_index(j >> 2, ni, j & 3)], x1 = h[split_index(j >> 2, ni, (j & 3) + 1)];
             const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
             const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
             const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
             const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
             // upper halves of (second, first) -> one dword, first in the low half
-            b.hi[s][jp] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-            b.mid[s][jp] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-            b.lo[s][jp] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+            b.hi[ni][jp] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+            b.mid[ni][jp] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+            b.lo[ni][jp] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
         }
 }
 
-// acc += A . B for one split 32x32 tile; `a` points at the tile's [2][3][64] 16-byte entries (LDS or global)
+// acc += A . B for one split 32 x 32 tile; `a` points at the tile's [2 mi][3 terms][64 lanes] 16-byte entries
+// (LDS or global memory)
 template <int TERMS>
 __device__ __forceinline__ f32x16 split_tile_mfma(f32x16 acc, const u32x4* a, const SplitB& b, int lane) {
     static_assert(TERMS == 6 || TERMS == 9, "6 or 9 partial products");
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const u32x4 ah = a[(s * 3 + 0) * 64 + lane], am = a[(s * 3 + 1) * 64 + lane], al = a[(s * 3 + 2) * 64 + lane];
+    for (int mi = 0; mi < 2; ++mi) {
+        const u32x4 ah = a[(mi * 3 + 0) * 64 + lane], am = a[(mi * 3 + 1) * 64 + lane], al = a[(mi * 3 + 2) * 64 + lane];
+        f32x4s c[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[ni][i] = acc[split_index(mi, ni, i)];
+        auto term = [&](const u32x4& at, const u32x4 (&bt)[2]) {
+            c[0] = MFMA_BF16(at, bt[0], c[0]);
+            c[1] = MFMA_BF16(at, bt[1], c[1]);
+        };
         if (TERMS == 9) {                                   // smallest terms first
-            acc = MFMA_BF16(al, b.lo[s], acc);
-            acc = MFMA_BF16(am, b.lo[s], acc);
-            acc = MFMA_BF16(al, b.mid[s], acc);
+            term(al, b.lo);
+            term(am, b.lo);
+            term(al, b.mid);
         }
-        acc = MFMA_BF16(ah, b.lo[s], acc);
-        acc = MFMA_BF16(al, b.hi[s], acc);
-        acc = MFMA_BF16(am, b.mid[s], acc);
-        acc = MFMA_BF16(ah, b.mid[s], acc);
-        acc = MFMA_BF16(am, b.hi[s], acc);
-        acc = MFMA_BF16(ah, b.hi[s], acc);
+        term(ah, b.lo);
+        term(al, b.hi);
+        term(am, b.mid);
+        term(ah, b.mid);
+        term(am, b.hi);
+        term(ah, b.hi);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[split_index(mi, ni, i)] = c[ni][i];
     }
     return acc;
 }
@@ -277,6 +305,85 @@ __device__ __forceinline__ void head_epilogue(const f32x16& lacc, const float* _
     if (half == 0 && w < n_windows) {
         *reinterpret_cast<float2*>(p_out + 2 * w) = make_float2(p0, p1);
         if (dec_out) dec_out[w] = (mode == VAD_DECIDE_THRESHOLD) ? (p1 >= threshold) : (p1 > p0);
+    }
+}
+
+// ---- the head in the split (16 x 16 sub-tile) layout ------------------------------------------------
+// Tile row p = 16 mi + 4 q + i of the float32 images (biases, lin1 / lin2 rows, the 2-row head's weights) sits at
+// element (p & 3) + 4 (p >> 3) of lane half (p >> 2) & 1: for a lane's four rows i = 0..3 that is half q & 1,
+// elements 4 (2 mi + (q >> 1)) + i, a contiguous float4.
+__device__ __forceinline__ int split_image_half(int q) { return q & 1; }
+__device__ __forceinline__ int split_image_elem(int q, int mi) { return 4 * (2 * mi + (q >> 1)); }
+
+// 2-row head on the vector ALU: the weights of rows 0 and 1 for the lane's eight tile rows
+struct SplitHeadWeights {
+    float2 w[8];
+};
+
+__device__ __forceinline__ void split_head_load(SplitHeadWeights& hw, const float* __restrict__ a1, int t, int lane) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            hw.w[4 * mi + i] = *reinterpret_cast<const float2*>(a1 + ((long)t * kHk + split_image_elem(q, mi) + i) * 64 +
+                                                                 32 * split_image_half(q));
+}
+
+// lacc[2 ni + o] += sum over the lane's rows of W[o][row] h[row] for window half ni
+__device__ __forceinline__ void split_head_step(f32x16& lacc, const SplitHeadWeights& hw, const f32x16& h) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                lacc[2 * ni] = fmaf(hw.w[4 * mi + i].x, h[split_index(mi, ni, i)], lacc[2 * ni]);
+                lacc[2 * ni + 1] = fmaf(hw.w[4 * mi + i].y, h[split_index(mi, ni, i)], lacc[2 * ni + 1]);
+            }
+}
+
+__device__ __forceinline__ float sum_over_q(float x) {          // over the four lanes 16 q + n that share a window
+    x += __shfl_xor(x, 16, 64);
+    return x + __shfl_xor(x, 32, 64);
+}
+
+// (ReLU, lin2) or the bias of lin; softmax over the 2 classes; decision.  Window half ni of lane 16 q + n is
+// window w_first + 16 ni; the lanes with q = 0 store.
+template <bool LARGE>
+__device__ __forceinline__ void split_head_epilogue(const f32x16& lacc, const float* __restrict__ tail, int lane, long w_first,
+                                                    long n_windows, float* __restrict__ p_out, uint8_t* __restrict__ dec_out,
+                                                    int mode, float threshold) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        float l0 = 0.0f, l1 = 0.0f;
+        if (LARGE) {
+            const int hh = split_image_half(q);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = split_image_elem(q, mi) + i;
+                    const float v = fmaxf(lacc[split_index(mi, ni, i)] + tail[hh * 16 + e], 0.0f);
+                    l0 = fmaf(v, tail[32 + (0 * 2 + hh) * 16 + e], l0);
+                    l1 = fmaf(v, tail[32 + (1 * 2 + hh) * 16 + e], l1);
+                }
+            l0 = sum_over_q(l0) + tail[96];
+            l1 = sum_over_q(l1) + tail[97];
+        } else {
+            l0 = sum_over_q(lacc[2 * ni]) + tail[0];
+            l1 = sum_over_q(lacc[2 * ni + 1]) + tail[1];
+        }
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float inv = 1.0f / (e0 + e1);
+        const float p0 = e0 * inv, p1 = e1 * inv;
+        const long w = w_first + 16 * ni;
+        if (q == 0 && w < n_windows) {
+            *reinterpret_cast<float2*>(p_out + 2 * w) = make_float2(p0, p1);
+            if (dec_out) dec_out[w] = (mode == VAD_DECIDE_THRESHOLD) ? (p1 >= threshold) : (p1 > p0);
+        }
     }
 }
 
