@@ -201,11 +201,12 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
  * of the recurrence and of the 26-row head.  Process-wide; no counterpart in the reference.
  *   VAD_MATRIX_BF16X9  (default) every float32 operand is split exactly into three bfloat16 (x = hi + mid + lo)
  *                      and all nine partial products, each exact in float32, are accumulated in float32 on the
- *                      bf16 matrix pipe (v_mfma_f32_32x32x16_bf16): no operand or product is rounded, only the
+ *                      bf16 matrix pipe (v_mfma_f32_16x16x32_bf16): no operand or product is rounded, only the
  *                      accumulation is, as in a float32 FMA chain but in a different order and with the matrix
- *                      pipe's alignment: per K = 8 half of an instruction the exact products are aligned to the
- *                      largest one and kept to 25 bits before the sum is added to C and rounded to nearest
- *                      (measured by tools/probes/mfma_bf16_accum.hip), which bounds a K = 32 dot product's error
+ *                      pipe's alignment: the instruction adds its K = 32 in four chained groups of 8; in each the
+ *                      exact products are aligned to the largest one and kept to 25 bits before the sum is added
+ *                      to C and rounded to nearest (measured by tools/probes/mfma_bf16_accum_k32.hip), which
+ *                      bounds a K = 32 dot product's error
  *                      by about 68 * 2^-24 * the largest magnitude in the chain (float32 FMA chain: 30 * 2^-24).
  *   VAD_MATRIX_F32     v_mfma_f32_32x32x2_f32: a float32 FMA chain in k order, bit-identical to what every other
  *                      path of this library computes (dense batches, other strides, sampled windows).
