@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
     unsigned char* wbase = smem + wave * (kWaveLdsBytes + kRingBytes);
     float2* ex = reinterpret_cast<float2*>(wbase);                          // exchange 1 / 2, power spectrum
     float* en = reinterpret_cast<float*>(wbase + kExBytes);                  // [4 frames][32]
+    float* parts = reinterpret_cast<float*>(wbase + kExBytes + kEnBytes);   // [2][64]
     float* ring = reinterpret_cast<float*>(wbase + kWaveLdsBytes);           // [kRingRows][12]
     const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
     const double* dctb = reinterpret_cast<const double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
@@ -175,8 +176,11 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
                 // 30 live registers and the third wave per SIMD already covers the load latency)
                 RawFrame raw;
                 frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
-                frame_energies(raw, tws, pow_off, off512, K, ex, en + it * 32);
+                if (it > 0) filter_sums(parts, en + (it - 1) * 32, K);      // the previous frame's, under this load
+                frame_energies(raw, tws, pow_off, off512, K, ex, parts);
             }
+            filter_sums(parts, en + (nfr - 1) * 32, K);
+            wave_lds_fence();
             const int tl = fresh_lane();                                    // see fresh_lane: nothing of the tail's
             cepstra_tail(en, reinterpret_cast<double*>(wbase), dctb, nfr, tl, ring, (fbase - first) % kRingRows, 1,
                          kRingRows);                                        // addressing stays live over the frames

@@ -117,10 +117,12 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 
-// Per-wave LDS: [exchange 1 / 2, then power spectrum + partial sums, then log energies][filter energies of 4 frames]
-constexpr int kPartOffset = kPowFloats;        // float offset of the 2 x 64 mel partial sums inside the exchange region
-constexpr int kWaveLdsBytes = kExBytes + kFramesPerWave * 32 * 4;
-static_assert((kPartOffset + 128) * 4 <= kExBytes, "power spectrum + partial sums must fit the exchange region");
+// Per-wave LDS: [exchange 1 / 2, then power spectrum, then log energies][filter energies of 4 frames][2 x 64 mel
+// partial sums of the last frame: outside the exchange region, they are summed while the next frame loads]
+constexpr int kEnBytes = kFramesPerWave * 32 * 4;
+constexpr int kPartBytes = 2 * 64 * 4;
+constexpr int kWaveLdsBytes = kExBytes + kEnBytes + kPartBytes;
+static_assert(kPowFloats * 4 <= kExBytes, "the power spectrum must fit the exchange region");
 
 // Block-shared LDS image of the W1024 twiddles tw1[12][64] (the head of MfccTables); the other two sets
 // live in registers.
@@ -174,7 +176,8 @@ __device__ __forceinline__ void frame_load(RawFrame& raw, const int* __restrict_
     }
 }
 
-// One frame from its raw input to the 26 mel filter energies in en_slot[0..25].
+// One frame from its raw input to the mel partial sums of the 64 run-lanes in parts[0..63] (rising edges) and
+// parts[64..127] (falling edges); filter_sums turns them into the 26 filter energies.
 // The twiddle factors are read from `tws`, a block-shared LDS image of the tables, where they are used
 // instead of living in ~70 registers: the kernel is latency-bound (in-order waves stalling on their own
 // LDS exchanges), three waves per SIMD need the register file, and reading them from global memory
@@ -184,12 +187,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, const u32x4* pow_off, int off512,
-                                               const LaneConst& K, float2* ex, float* en_slot) {
+                                               const LaneConst& K, float2* ex, float* parts) {
     const int lane = fresh_lane();
     const int k1l = lane >> 4, q1l = lane & 15;
     float* pw = reinterpret_cast<float*>(ex);                               // aliases ex once exchange 2 is read
-    float* part_r = pw + kPartOffset;
-    float* part_f = part_r + 64;
 
     // ---- pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj ----
     float2 v[16];
@@ -288,21 +289,23 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
             sr = fmaf(p, fmaf((float)i, K.run_inv, K.run_w0), sr);
             sf = fmaf(p, fmaf(-(float)i, K.run_inv, K.run_f0), sf);
         }
-        part_r[lane] = sr;
-        part_f[lane] = sf;
+        parts[lane] = sr;
+        parts[64 + lane] = sf;
     }
-    wave_lds_fence();
+}
 
-    // ---- filter f = rising parts of segment f + falling parts of segment f+1, fixed order ----
-    {
-        float e = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) e += (i < K.rise_n) ? part_r[min(K.rise_first + i, 63)] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) e += (i < K.fall_n) ? part_f[min(K.fall_first + i, 63)] : 0.0f;
-        if (lane < 32) en_slot[lane] = e;
-    }
+// filter f = rising parts of segment f + falling parts of segment f+1, in a fixed order; en_slot[0..25].
+// Called after the NEXT frame's samples have been requested (or before the tail): the LDS round trip of the
+// partial sums passes under that wait instead of stalling the wave at the end of every frame.
+__device__ __forceinline__ void filter_sums(const float* parts, float* en_slot, const LaneConst& K) {
     wave_lds_fence();
+    const int lane = fresh_lane();
+    float e = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) e += (i < K.rise_n) ? parts[min(K.rise_first + i, 63)] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) e += (i < K.fall_n) ? parts[64 + min(K.fall_first + i, 63)] : 0.0f;
+    if (lane < 32) en_slot[lane] = e;
 }
 
 // A double-precision constant the compiler cannot see through: the tail below sits inside the kernel's frame
