@@ -253,12 +253,18 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     const int paddr = plane * 4;
     const u32x4 off_lo = pow_off[lane], off_hi = pow_off[64 + lane];       // 8 + 8 packed 16-bit byte offsets
     unsigned char* pwb = reinterpret_cast<unsigned char*>(pw);
+    // all sixteen cross-lane reads are issued ahead of their use: their latency is paid once
+    float2 partner[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        partner[u].x = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(v[15 - u].x)));
+        partner[u].y = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(v[15 - u].y)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         const float2 a = v[jj];
-        float2 b;
-        b.x = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(v[15 - jj].x)));
-        b.y = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(v[15 - jj].y)));
+        float2 b = partner[jj];
         if (lane == 0) b = v[(16 - jj) & 15];
         const float2 e = make_float2(a.x + b.x, a.y - b.y);
         const float2 o = make_float2(a.x - b.x, a.y + b.y);
