@@ -350,6 +350,31 @@ def test_split_bf16_matrix_modes(vad, kind, mode):
         vad.set_matrix_mode('fp8')
 
 
+@pytest.mark.parametrize('kind', ['gru_large', 'gru_small', 'lstm_large', 'lstm_small'])
+def test_split_kernels_at_ragged_window_counts(vad, kind):
+    """Window counts around the kernels' 16-window halves, 32-window waves and 224 / 256-window blocks: every
+    window scored once, within the bar of the oracle, and nothing written past the last window."""
+    ref = models_ref.make_model(kind)
+    net = _gpu_model(vad, kind, ref)
+    rng = np.random.default_rng(7)
+    feat_np = rng.normal(0, 6, size=(600, 24)).astype(np.float32)
+    feat = torch.tensor(feat_np).cuda()
+    windows = torch.stack([torch.from_numpy(feat_np[i:i + 30]) for i in range(571)])
+    with torch.no_grad():
+        y = ref(windows).numpy()
+    prev = vad.set_matrix_mode('bf16x9')
+    try:
+        for n in (1, 15, 16, 17, 31, 32, 33, 223, 224, 225, 255, 256, 257, 571):
+            p = torch.full((n + 3, 2), -7.0, device='cuda')
+            d = torch.full((n + 3,), 9, dtype=torch.uint8, device='cuda')
+            net.score(feat[:n + 29], window_stride=24, n_windows=n, out=p[:n], decisions=d[:n])
+            assert np.abs(p[:n].cpu().numpy() - y[:n]).max() <= ATOL, n
+            assert bool((p[n:] == -7.0).all()) and bool((d[n:] == 9).all()), n
+            assert bool((d[:n] <= 1).all()), n
+    finally:
+        vad.set_matrix_mode(prev)
+
+
 def test_calls_follow_the_current_stream(vad):
     """Every entry point launches on the caller's stream: two side streams working on different inputs at
     the same time give the results of the default stream (the library keeps no mutable device state)."""
