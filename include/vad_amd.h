@@ -183,8 +183,10 @@ int vad_densenet_forward_f32(const float* x_dev, int64_t n_windows, int64_t wind
  * configuration, hidden = 90; no class in the reference) over stride-1 windows (window_stride == 24).  The head
  * of every step's accumulation chain, bias + W_ih x_row, depends on the feature row only; with a workspace
  * it is computed once per row instead of once per window and step (the recurrent weights of such a model fill
- * the LDS, so unlike the 30-unit models' kernel it cannot keep the projected rows on chip).  Results are
- * bit-identical to vad_gru_forward_f32; other models and strides ignore the workspace.
+ * the LDS, so unlike the 30-unit models' kernel it cannot keep the projected rows on chip).  In the
+ * VAD_MATRIX_F32 mode the results are bit-identical to vad_gru_forward_f32; in the bf16 matrix modes (below) the
+ * workspace path forms the recurrent and head products on the bf16 matrix pipe like the 30-unit models' stride-1
+ * kernels.  Other models and strides ignore the workspace.
  *   workspace_dev    caller-owned device memory, 16-byte aligned; any size: the windows are processed in chunks
  *                    of as many as the workspace has rows for (288 floats per row for hidden 65..96, 192 for
  *                    33..64; at least 30 rows, else the workspace is not used).  Contents are scratch.
@@ -197,8 +199,9 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
                            void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /*
- * How the stride-1 (window_stride == 24) GRU / LSTM kernels with hidden <= 32 form the float32 products
- * of the recurrence and of the 26-row head.  Process-wide; no counterpart in the reference.
+ * How the stride-1 (window_stride == 24) GRU / LSTM kernels with hidden <= 32, and the wider GRUs' stride-1
+ * workspace path (vad_gru_forward_ws_f32), form the float32 products of the recurrence and of the 26-row head.
+ * Process-wide; no counterpart in the reference.
  *   VAD_MATRIX_BF16X9  (default) every float32 operand is split exactly into three bfloat16 (x = hi + mid + lo)
  *                      and all nine partial products, each exact in float32, are accumulated in float32 on the
  *                      bf16 matrix pipe (v_mfma_f32_16x16x32_bf16): no operand or product is rounded, only the
@@ -211,7 +214,7 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
  *   VAD_MATRIX_F32     v_mfma_f32_32x32x2_f32: a float32 FMA chain in k order, bit-identical to what every other
  *                      path of this library computes (dense batches, other strides, sampled windows).
  *   VAD_MATRIX_BF16X6  as BF16X9 without the three smallest partial products (<= 2^-23 of a product).
- * Other strides, sampled windows, wider GRUs and DenseNet always compute as VAD_MATRIX_F32.
+ * Other strides, sampled windows, wider GRUs without a workspace and DenseNet always compute as VAD_MATRIX_F32.
  */
 #define VAD_MATRIX_F32 0
 #define VAD_MATRIX_BF16X6 1

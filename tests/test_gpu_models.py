@@ -164,10 +164,11 @@ def test_gru_other_hidden_sizes(vad, hidden, large, f32_matrix_mode):
 
 
 @pytest.mark.parametrize('hidden,large', [(90, True), (64, False), (40, True)])
-def test_wide_gru_workspace_chunks(vad, hidden, large):
+def test_wide_gru_workspace_chunks(vad, hidden, large, f32_matrix_mode):
     """vad_gru_forward_ws_f32: the stride-1 path of wide GRUs projects each feature row once into a caller-owned
     workspace.  Whatever the workspace size (one chunk, several ragged chunks, too small to be used at all) the
-    posteriors equal those of the plain entry point bit for bit."""
+    posteriors equal those of the plain entry point bit for bit (float32 matrix mode; the bf16 modes of the
+    workspace path: test_wide_gru_split_kernel)."""
     import ctypes
     from voice_activity_detection_amd import _lib
     L = vad.lib()
@@ -373,6 +374,49 @@ def test_split_kernels_at_ragged_window_counts(vad, kind):
             assert bool((d[:n] <= 1).all()), n
     finally:
         vad.set_matrix_mode(prev)
+
+
+@pytest.mark.parametrize('mode', ['bf16x9', 'bf16x6'])
+@pytest.mark.parametrize('hidden,large', [(90, True), (90, False), (64, True), (40, False), (33, True)])
+def test_wide_gru_split_kernel(vad, hidden, large, mode):
+    """Stride-1 windows of the wide GRU with the products on the bf16 matrix pipe: within the bar of the float32
+    oracle and of the float32-MFMA kernel, at window counts around the kernel's 16 / 32 / 128-window boundaries,
+    through a workspace that forces several chunks, and without writing past the last window."""
+    ref = models_ref.make_model('gru_large' if large else 'gru_small', hidden=hidden)
+    net = vad.Net(large=large, lstm=False, hidden=hidden)
+    net.load_state_dict(ref.state_dict())
+    rng = np.random.default_rng(hidden)
+    feat_np = rng.normal(0, 6, size=(460, 24)).astype(np.float32)
+    feat_np[100:130] = 0.0
+    feat_np[300:303] *= 25.0
+    feat = torch.tensor(feat_np).cuda()
+    prev = vad.set_matrix_mode('f32')
+    try:
+        p32, _ = net.score(feat, window_stride=24)
+        vad.set_matrix_mode(mode)
+        for n in (1, 15, 16, 17, 31, 32, 33, 127, 128, 129, 431):
+            p = torch.full((n + 3, 2), -7.0, device='cuda')
+            d = torch.full((n + 3,), 9, dtype=torch.uint8, device='cuda')
+            net.score(feat[:n + 29], window_stride=24, n_windows=n, out=p[:n], decisions=d[:n])
+            assert float((p[:n] - p32[:n]).abs().max()) <= ATOL, n
+            assert bool((p[n:] == -7.0).all()) and bool((d[n:] == 9).all()), n
+            assert bool((d[:n] <= 1).all()), n
+        cap = type(net).WORKSPACE_CAP
+        try:
+            type(net).WORKSPACE_CAP = 100 * 3 * ((hidden + 31) // 32) * 32 * 4       # 100 rows: 71 windows per chunk
+            net._ws = None
+            p_chunks, _ = net.score(feat, window_stride=24)
+        finally:
+            type(net).WORKSPACE_CAP = cap
+            net._ws = None
+        p_whole, _ = net.score(feat, window_stride=24)
+        assert torch.equal(p_chunks, p_whole)
+    finally:
+        vad.set_matrix_mode(prev)
+    windows = torch.stack([torch.from_numpy(feat_np[i:i + 30]) for i in range(431)])
+    with torch.no_grad():
+        y = ref(windows).numpy()
+    assert np.abs(p_whole.cpu().numpy() - y).max() <= ATOL
 
 
 def test_calls_follow_the_current_stream(vad):

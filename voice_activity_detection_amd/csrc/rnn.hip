@@ -603,6 +603,224 @@ __global__ __launch_bounds__(256, 1) void gru_wide_stream_kernel(const float* __
     head_epilogue<LARGE>(lacc, blob + L.tail, half, w, n_windows, p_out, dec_out, mode, threshold);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The stride-1 wide GRU with the recurrent product and the head on the bf16 matrix pipe (float32 operands split
+// exactly into three bf16, rnn_device.h), in the 16 x 16 sub-tile layout of rnn_stream_split_kernel: lane 16 q + n
+// holds, of every 32-unit tile, tile rows 16 mi + 4 q + i of windows n and 16 + n.  The recurrent products read the
+// split copy of the state, so a tile's new state overwrites the old one in place.  The split A operands of all
+// gates fill the LDS except the last gate's lo terms, which come from the weight blob (L2) like the head's.
+// Projected rows come from row_project_kernel's workspace and move down one lane per step inside each 16-lane row
+// (the row of window 15 comes from the lane's second window, that of window 31 is loaded).
+
+template <int UT>
+struct WideSplitB {
+    u32x4 hi[UT][2], mid[UT][2], lo[UT][2];      // [k-block][window half]
+};
+
+template <int UT>
+__device__ __forceinline__ void wide_split_state(WideSplitB<UT>& b, const f32x16 (&h)[UT]) {
+#pragma unroll
+    for (int kb = 0; kb < UT; ++kb) {
+        SplitB one;
+        split_state(one, h[kb]);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            b.hi[kb][ni] = one.hi[ni];
+            b.mid[kb][ni] = one.mid[ni];
+            b.lo[kb][ni] = one.lo[ni];
+        }
+    }
+}
+
+// c[ni] += A (hi, mid, lo) . B (k-block kb): the TERMS partial products, smallest first
+template <int UT, int TERMS>
+__device__ __forceinline__ void wide_split_terms(f32x4s (&c)[2], const u32x4& ah, const u32x4& am, const u32x4& al,
+                                                 const WideSplitB<UT>& b, int kb) {
+    auto term = [&](const u32x4& at, const u32x4 (&bt)[2]) {
+        c[0] = MFMA_BF16(at, bt[0], c[0]);
+        c[1] = MFMA_BF16(at, bt[1], c[1]);
+    };
+    if (TERMS == 9) {
+        term(al, b.lo[kb]);
+        term(am, b.lo[kb]);
+        term(al, b.mid[kb]);
+    }
+    term(ah, b.lo[kb]);
+    term(al, b.hi[kb]);
+    term(am, b.mid[kb]);
+    term(ah, b.mid[kb]);
+    term(am, b.hi[kb]);
+    term(ah, b.hi[kb]);
+}
+
+// Row registers of one (gate, tile): lanes 0..14 of a 16-lane row take the value of the next lane, lane 15 that of
+// lane 0 of the second window's register (x1 rotated), whose own lane 15 is left for the caller to load.
+__device__ __forceinline__ void rows_down(float& x0, float& x1) {
+    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x1), 0x12F /* row_ror:15 */, 0xF, 0xF, false);
+    x0 = __int_as_float(__builtin_amdgcn_update_dpp(r, __float_as_int(x0), 0x101 /* row_shl:1 */, 0xF, 0xF, false));
+    x1 = __int_as_float(r);
+}
+
+template <bool LARGE, int UT, int TERMS>
+__global__ __launch_bounds__(256, 1) void gru_wide_split_kernel(const float* __restrict__ gi, long n_windows,
+                                                                const float* __restrict__ blob, float* __restrict__ p_out,
+                                                                uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    extern __shared__ __align__(16) float lds[];
+    const NetLayout L = net_layout(false, LARGE, UT);
+    constexpr int kLdsEntries = wide_split_lds_entries(UT);
+    constexpr int kHm = wide_split_hm_entries(UT);
+    const u32x4* a_glob = reinterpret_cast<const u32x4*>(blob + L.s_hh);
+    {
+        u32x4* dst = reinterpret_cast<u32x4*>(lds);
+        for (int i = threadIdx.x; i < kLdsEntries * 64; i += blockDim.x) dst[i] = a_glob[i];
+        float* cbw = lds + kLdsEntries * kSplitEntry;
+        for (int i = threadIdx.x; i < 4 * UT * 32; i += blockDim.x) cbw[i] = blob[L.cb + i];
+    }
+    __syncthreads();
+    const u32x4* a_lds = reinterpret_cast<const u32x4*>(lds);
+    const float* cb = lds + kLdsEntries * kSplitEntry;
+    const u32x4* a_head = reinterpret_cast<const u32x4*>(blob + L.s_head);
+    const float* a1 = blob + L.head;
+
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, n = lane & 15;
+    const long tile = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (tile * kWindowsPerWave >= n_windows) return;
+    const long w_first = tile * kWindowsPerWave + n;             // the lane's windows: w_first and w_first + 16
+    const long last_row = n_windows + kT - 2;                    // the workspace holds n_windows + 29 rows
+    constexpr int kRow = 3 * UT * 32;                            // floats per projected row
+    // tile rows 16 mi + 4 q + i of a 32-row image stored per lane half (hh, element): hh = q & 1, elements
+    // 4 (2 mi + (q >> 1)) + i, i.e. float offset 16 hh + that
+    const int chunk = 16 * split_image_half(q) + split_image_elem(q, 0);            // mi = 0; mi = 1 is 8 floats on
+
+    f32x16 h[UT], lacc, row[3 * UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) h[u][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.0f;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {                             // step 0: rows w_first and w_first + 16
+        const long r0 = w_first + 16 * ni;
+        const float* src = gi + (r0 < last_row ? r0 : last_row) * kRow + chunk;
+#pragma unroll
+        for (int gm = 0; gm < 3 * UT; ++gm)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const float4 v = *reinterpret_cast<const float4*>(src + gm * 32 + 8 * mi);
+                row[gm][split_index(mi, ni, 0)] = v.x; row[gm][split_index(mi, ni, 1)] = v.y;
+                row[gm][split_index(mi, ni, 2)] = v.z; row[gm][split_index(mi, ni, 3)] = v.w;
+            }
+    }
+    WideSplitB<UT> b;
+
+    for (int t = 0; t < kT; ++t) {
+        // the row the wave's last window consumes at the next step
+        const long rn = tile * kWindowsPerWave + 31 + t + 1;
+        const float* nxt = gi + (rn < last_row ? rn : last_row) * kRow + chunk;
+        SplitHeadWeights hw[UT];                                 // 2-row head: vector ALU, float32 weights
+        if (!LARGE) {
+#pragma unroll
+            for (int kb = 0; kb < UT; ++kb) split_head_load(hw[kb], a1 + kb * kHk * 64, t * UT, lane);
+        }
+#pragma unroll
+        for (int mt = 0; mt < UT; ++mt) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = row[g * UT + mt];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {                     // b_hn
+                const float4 v = *reinterpret_cast<const float4*>(cb + (3 * UT + mt) * 32 + chunk + 8 * mi);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[3][split_index(mi, ni, 0)] = v.x; acc[3][split_index(mi, ni, 1)] = v.y;
+                    acc[3][split_index(mi, ni, 2)] = v.z; acc[3][split_index(mi, ni, 3)] = v.w;
+                }
+            }
+            if (t > 0) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    f32x16& dst = acc[g == 2 ? 3 : g];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        f32x4s c[2];
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) c[ni][i] = dst[split_index(mi, ni, i)];
+#pragma unroll
+                        for (int kb = 0; kb < UT; ++kb) {
+                            const int base = wide_split_base(UT, g, mt, mi, kb);
+                            const u32x4 ah = a_lds[(base * 2 + 0) * 64 + lane], am = a_lds[(base * 2 + 1) * 64 + lane];
+                            const u32x4 al = g < 2 ? a_lds[(kHm + base) * 64 + lane] : a_glob[(kHm + base) * 64 + lane];
+                            wide_split_terms<UT, TERMS>(c, ah, am, al, b, kb);
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dst[split_index(mi, ni, i)] = c[ni][i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float r = sigmoid_pre(acc[0][i]);
+                const float z = sigmoid_pre(acc[1][i]);
+                const float nn = tanh_pre(fmaf(r, acc[3][i], acc[2][i]));
+                h[mt][i] = fmaf(z, h[mt][i] - nn, nn);           // in place: the products read the split copy
+            }
+            if (t + 1 < kT) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    f32x16& rv = row[g * UT + mt];
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float x0 = rv[split_index(mi, 0, i)], x1 = rv[split_index(mi, 1, i)];
+                            rows_down(x0, x1);
+                            rv[split_index(mi, 0, i)] = x0;
+                            rv[split_index(mi, 1, i)] = x1;
+                        }
+                    if (n == 15) {                               // in flight until the next step
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi) {
+                            const float4 v = *reinterpret_cast<const float4*>(nxt + (g * UT + mt) * 32 + 8 * mi);
+                            rv[split_index(mi, 1, 0)] = v.x; rv[split_index(mi, 1, 1)] = v.y;
+                            rv[split_index(mi, 1, 2)] = v.z; rv[split_index(mi, 1, 3)] = v.w;
+                        }
+                    }
+                }
+            }
+        }
+        wide_split_state<UT>(b, h);                              // for this step's head and the next step's gates
+        if (LARGE) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                f32x4s c[2];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) c[ni][i] = lacc[split_index(mi, ni, i)];
+#pragma unroll
+                for (int kb = 0; kb < UT; ++kb) {
+                    const u32x4* e = a_head + (size_t)(((t * 2 + mi) * UT + kb) * 3) * 64 + lane;
+                    wide_split_terms<UT, TERMS>(c, e[0], e[64], e[128], b, kb);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) lacc[split_index(mi, ni, i)] = c[ni][i];
+            }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < UT; ++kb) split_head_step(lacc, hw[kb], h[kb]);
+        }
+    }
+    split_head_epilogue<LARGE>(lacc, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold);
+}
+
 template <typename K>
 int allow_lds(K kernel, int floats) {
     VAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -616,6 +834,15 @@ int allow_wide() {
     int rc = allow_lds(&gru_wide_kernel<LARGE, UT, KL>, L.head);
     if (rc != VAD_OK) return rc;
     return allow_lds(&gru_wide_stream_kernel<LARGE, UT, KL>, L.head - L.a_hh);
+}
+
+constexpr int wide_split_lds_floats(int ut) { return wide_split_lds_entries(ut) * kSplitEntry + 4 * ut * 32; }
+
+template <bool LARGE, int UT>
+int allow_wide_split() {
+    int rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, 9>, wide_split_lds_floats(UT));
+    if (rc != VAD_OK) return rc;
+    return allow_lds(&gru_wide_split_kernel<LARGE, UT, 6>, wide_split_lds_floats(UT));
 }
 
 }  // namespace
@@ -650,6 +877,9 @@ int ensure_rnn_attrs() {
         (rc = allow_wide<true, 3, 13>()) || (rc = allow_wide<false, 2, 16>()) || (rc = allow_wide<true, 2, 16>()) ||
         (rc = allow_wide<false, 3, 16>()) || (rc = allow_wide<true, 3, 16>()))
         return rc;
+    if ((rc = allow_wide_split<false, 2>()) || (rc = allow_wide_split<true, 2>()) || (rc = allow_wide_split<false, 3>()) ||
+        (rc = allow_wide_split<true, 3>()))
+        return rc;
     done[dev] = true;
     return VAD_OK;
 }
@@ -677,6 +907,8 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
         // chunk's projection from overwriting rows still in use)
         const long chunk = ws_rows - (kT - 1);
         const size_t lds_bytes = (size_t)(L.head - L.a_hh) * sizeof(float);
+        const size_t split_lds_bytes = (size_t)wide_split_lds_floats(UT) * sizeof(float);
+        const int matrix_mode = g_matrix_mode.load(std::memory_order_relaxed);
         for (long w0 = 0; w0 < n_windows; w0 += chunk) {
             const long nw = n_windows - w0 < chunk ? n_windows - w0 : chunk;
             const long rows = nw + kT - 1;
@@ -684,8 +916,15 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
             VAD_REQUIRE(pblocks <= 0x7FFFFFFFL && blocks <= 0x7FFFFFFFL, "too many windows for one launch");
             hipLaunchKernelGGL((row_project_kernel<UT>), dim3((unsigned)pblocks), dim3(256), 0, st, x + w0 * kF, rows, blob,
                                ws.ptr);
-            hipLaunchKernelGGL((gru_wide_stream_kernel<LARGE, UT, KL>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
-                               lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+            if (matrix_mode == VAD_MATRIX_BF16X9)
+                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 9>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
+                                   split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+            else if (matrix_mode == VAD_MATRIX_BF16X6)
+                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 6>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
+                                   split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+            else
+                hipLaunchKernelGGL((gru_wide_stream_kernel<LARGE, UT, KL>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
+                                   lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
             VAD_HIP_CHECK(hipGetLastError());
         }
         return VAD_OK;
@@ -922,6 +1161,59 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
         };
         for (int g = 0; g < G; ++g) split_tile(blob + L.a_hh + g * kHk * 64, blob + L.s_hh + g * kSplitTile);
         for (int t = 0; t < kT; ++t) split_tile(blob + L.head + t * kHk * 64, blob + L.s_head + t * kSplitTile);
+    } else {
+        // wide GRU: bf16 (hi, mid, lo) A operands of v_mfma_f32_16x16x32_bf16.  Entry (rows 16 mi .. + 15 of unit
+        // tile mt, k-block kb): lane l = 16 q + m holds tile row 16 mi + m of tile mt and, as k-slots 8 q + j, the tile
+        // rows split_row_of_k_slot(q, j) of tile kb (rnn_device.h); rows and slots that carry no unit stay zero.
+        auto put = [&](float x, uint16_t* e_hi, uint16_t* e_mid, uint16_t* e_lo, int at) {
+            uint32_t bits;
+            memcpy(&bits, &x, 4);
+            const uint32_t hb = bits & 0xFFFF0000u;
+            float hi;
+            memcpy(&hi, &hb, 4);
+            const float r1 = x - hi;
+            memcpy(&bits, &r1, 4);
+            const uint32_t mb = bits & 0xFFFF0000u;
+            float mid;
+            memcpy(&mid, &mb, 4);
+            const float r2 = r1 - mid;
+            memcpy(&bits, &r2, 4);
+            e_hi[at] = (uint16_t)(hb >> 16);
+            e_mid[at] = (uint16_t)(mb >> 16);
+            e_lo[at] = (uint16_t)(bits >> 16);
+        };
+        auto entry = [&](int off, int index) { return reinterpret_cast<uint16_t*>(blob + off + (size_t)index * kSplitEntry); };
+        for (int g = 0; g < 3; ++g)
+            for (int mt = 0; mt < UT; ++mt)
+                for (int mi = 0; mi < 2; ++mi)
+                    for (int kb = 0; kb < UT; ++kb) {
+                        const int base = wide_split_base(UT, g, mt, mi, kb);
+                        uint16_t* e_hi = entry(L.s_hh, base * 2 + 0);
+                        uint16_t* e_mid = entry(L.s_hh, base * 2 + 1);
+                        uint16_t* e_lo = entry(L.s_hh, wide_split_hm_entries(UT) + base);
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int m = unit_at(mt, 16 * mi + (lane & 15));
+                                const int u = unit_at(kb, split_row_of_k_slot(lane >> 4, j));
+                                const float x = (m < 0 || u < 0) ? 0.0f : (float)(gate_scale(g) * (double)w_hh[(g * H + m) * H + u]);
+                                put(x, e_hi, e_mid, e_lo, lane * 8 + j);
+                            }
+                    }
+        for (int t = 0; t < kT; ++t)
+            for (int mi = 0; mi < 2; ++mi)
+                for (int kb = 0; kb < UT; ++kb) {
+                    const int base = ((t * 2 + mi) * UT + kb) * 3;
+                    uint16_t* e_hi = entry(L.s_head, base + 0);
+                    uint16_t* e_mid = entry(L.s_head, base + 1);
+                    uint16_t* e_lo = entry(L.s_head, base + 2);
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int o = 16 * mi + (lane & 15);
+                            const int u = unit_at(kb, split_row_of_k_slot(lane >> 4, j));
+                            const float x = (o < rows && u >= 0) ? hw[o * (kT * H) + t * H + u] : 0.0f;
+                            put(x, e_hi, e_mid, e_lo, lane * 8 + j);
+                        }
+                }
     }
     return VAD_OK;
 }

@@ -29,12 +29,25 @@ struct NetLayout {
     int cb;           // [4][ut][2][16]             accumulator initial values (biases), per lane half
     int head;         // a1 [30][ut*16][64]         A operands of lin1 (large) or lin (small, rows 0-1)
     int tail;         // large: b1e [2][16], w2e [2][2][16], b2 [2] (+2 pad); small: bl [2] (+2 pad)
-    int s_hh;         // ut == 1 only: [gates][2][3][64] x 8 bf16   a_hh split into bf16 (hi, mid, lo) A operands
-    int s_head;       // ut == 1 only: [30][2][3][64] x 8 bf16      the head's A operands, split the same way
+    int s_hh;         // ut == 1: [gates][2][3][64] x 8 bf16   a_hh split into bf16 (hi, mid, lo) A operands;
+                      // ut > 1 (GRU): wide_split_gate_entries(ut) entries of [64] x 8 bf16, order above
+    int s_head;       // ut == 1: [30][2][3][64] x 8 bf16      the head's A operands, split the same way;
+                      // ut > 1: [30][2 mi][ut kb][3 terms][64] x 8 bf16
     int total;
 };
 
 constexpr int kSplitTile = 2 * 3 * 64 * 4;   // dwords of one split 32x32 A tile: 2 halves of 16 rows, 3 terms, 16 B per lane
+constexpr int kSplitEntry = 64 * 4;          // dwords of one bf16 A operand of v_mfma_f32_16x16x32_bf16 (16 rows x 32 k)
+
+// GRU with ut > 1 unit tiles: the split recurrent operands are entries (gate g, unit tile mt, row half mi, k-block kb,
+// term) in two sections, first hi and mid of everything, then the lo terms gate by gate (r, z, n): the wide split
+// kernel keeps everything but the last gate's lo terms in LDS.
+__host__ __device__ constexpr int wide_split_hm_entries(int ut) { return 3 * ut * 2 * ut * 2; }
+__host__ __device__ constexpr int wide_split_gate_entries(int ut) { return 3 * ut * 2 * ut * 3; }
+__host__ __device__ constexpr int wide_split_lds_entries(int ut) { return wide_split_hm_entries(ut) + 2 * ut * 2 * ut; }
+__host__ __device__ constexpr int wide_split_base(int ut, int g, int mt, int mi, int kb) {
+    return (((g * ut + mt) * 2 + mi) * ut + kb);
+}
 
 __host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 1) {
     NetLayout L;
@@ -46,8 +59,8 @@ __host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 
     L.head = L.cb + 4 * ut * 2 * 16;
     L.tail = L.head + kT * ut * kHk * 64;
     L.s_hh = L.tail + (large ? (2 * 16 + 2 * 2 * 16 + 4) : 4);
-    L.s_head = L.s_hh + (ut == 1 ? L.gates * kSplitTile : 0);
-    L.total = L.s_head + (ut == 1 ? kT * kSplitTile : 0);
+    L.s_head = L.s_hh + (ut == 1 ? L.gates * kSplitTile : wide_split_gate_entries(ut) * kSplitEntry);
+    L.total = L.s_head + (ut == 1 ? kT * kSplitTile : kT * 2 * ut * 3 * kSplitEntry);
     return L;
 }
 
