@@ -612,33 +612,45 @@ __global__ __launch_bounds__(256, 1) void gru_wide_stream_kernel(const float* __
 // Projected rows come from row_project_kernel's workspace and move down one lane per step inside each 16-lane row
 // (the row of window 15 comes from the lane's second window, that of window 31 is loaded).
 
-template <int UT>
+// NI = window halves per lane: 2 -> a wave owns 32 windows and runs alone on its SIMD (512 registers), 1 -> 16
+// windows per wave, two waves per SIMD whose matrix and vector phases overlap.
+template <int UT, int NI>
 struct WideSplitB {
-    u32x4 hi[UT][2], mid[UT][2], lo[UT][2];      // [k-block][window half]
+    u32x4 hi[UT][NI], mid[UT][NI], lo[UT][NI];      // [k-block][window half]
 };
 
-template <int UT>
-__device__ __forceinline__ void wide_split_state(WideSplitB<UT>& b, const f32x16 (&h)[UT]) {
+// state of one 32-unit tile: [mi][ni] groups of the lane's four tile rows
+template <int NI>
+struct WideTile {
+    f32x4s v[2][NI];
+};
+
+template <int UT, int NI>
+__device__ __forceinline__ void wide_split_state(WideSplitB<UT, NI>& b, const WideTile<NI> (&h)[UT]) {
 #pragma unroll
-    for (int kb = 0; kb < UT; ++kb) {
-        SplitB one;
-        split_state(one, h[kb]);
+    for (int kb = 0; kb < UT; ++kb)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            b.hi[kb][ni] = one.hi[ni];
-            b.mid[kb][ni] = one.mid[ni];
-            b.lo[kb][ni] = one.lo[ni];
-        }
-    }
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) {                            // k-slots 2 jp, 2 jp + 1 = rows (jp >> 1, 2 (jp & 1) ..)
+                const float x0 = h[kb].v[jp >> 1][ni][2 * (jp & 1)], x1 = h[kb].v[jp >> 1][ni][2 * (jp & 1) + 1];
+                const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
+                const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+                const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
+                const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+                b.hi[kb][ni][jp] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+                b.mid[kb][ni][jp] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+                b.lo[kb][ni][jp] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+            }
 }
 
 // c[ni] += A (hi, mid, lo) . B (k-block kb): the TERMS partial products, smallest first
-template <int UT, int TERMS>
-__device__ __forceinline__ void wide_split_terms(f32x4s (&c)[2], const u32x4& ah, const u32x4& am, const u32x4& al,
-                                                 const WideSplitB<UT>& b, int kb) {
-    auto term = [&](const u32x4& at, const u32x4 (&bt)[2]) {
-        c[0] = MFMA_BF16(at, bt[0], c[0]);
-        c[1] = MFMA_BF16(at, bt[1], c[1]);
+template <int UT, int NI, int TERMS>
+__device__ __forceinline__ void wide_split_terms(f32x4s (&c)[NI], const u32x4& ah, const u32x4& am, const u32x4& al,
+                                                 const WideSplitB<UT, NI>& b, int kb) {
+    auto term = [&](const u32x4& at, const u32x4 (&bt)[NI]) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) c[ni] = MFMA_BF16(at, bt[ni], c[ni]);
     };
     if (TERMS == 9) {
         term(al, b.lo[kb]);
@@ -653,18 +665,32 @@ __device__ __forceinline__ void wide_split_terms(f32x4s (&c)[2], const u32x4& ah
     term(ah, b.hi[kb]);
 }
 
-// Row registers of one (gate, tile): lanes 0..14 of a 16-lane row take the value of the next lane, lane 15 that of
-// lane 0 of the second window's register (x1 rotated), whose own lane 15 is left for the caller to load.
-__device__ __forceinline__ void rows_down(float& x0, float& x1) {
-    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x1), 0x12F /* row_ror:15 */, 0xF, 0xF, false);
-    x0 = __int_as_float(__builtin_amdgcn_update_dpp(r, __float_as_int(x0), 0x101 /* row_shl:1 */, 0xF, 0xF, false));
-    x1 = __int_as_float(r);
+// Row registers of one (gate, tile, mi, i): lanes 0..14 of a 16-lane row take the value of the next lane; lane 15
+// of the first window half takes lane 0 of the second half's register, and the last half's lane 15 is left for the
+// caller to load.
+template <int NI>
+__device__ __forceinline__ void rows_down(f32x4s (&x)[NI], int i) {
+    if (NI == 2) {
+        const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(x[NI - 1][i]), 0x12F /* row_ror:15 */, 0xF, 0xF, false);
+        x[0][i] = __int_as_float(__builtin_amdgcn_update_dpp(r, __float_as_int(x[0][i]), 0x101 /* row_shl:1 */, 0xF, 0xF, false));
+        x[NI - 1][i] = __int_as_float(r);
+    } else {
+        const int v = __float_as_int(x[0][i]);
+        x[0][i] = __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x101 /* row_shl:1 */, 0xF, 0xF, false));
+    }
 }
 
-template <bool LARGE, int UT, int TERMS>
-__global__ __launch_bounds__(256, 1) void gru_wide_split_kernel(const float* __restrict__ gi, long n_windows,
-                                                                const float* __restrict__ blob, float* __restrict__ p_out,
-                                                                uint8_t* __restrict__ dec_out, int mode, float threshold) {
+template <int NI>
+struct WideSplitCfg {
+    static constexpr int waves = 8 / NI;                         // per block: one or two per SIMD
+    static constexpr int wave_windows = 16 * NI;
+};
+
+template <bool LARGE, int UT, int TERMS, int NI>
+__global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_kernel(
+    const float* __restrict__ gi, long n_windows, const float* __restrict__ blob, float* __restrict__ p_out,
+    uint8_t* __restrict__ dec_out, int mode, float threshold) {
+    using C = WideSplitCfg<NI>;
     extern __shared__ __align__(16) float lds[];
     const NetLayout L = net_layout(false, LARGE, UT);
     constexpr int kLdsEntries = wide_split_lds_entries(UT);
@@ -684,40 +710,41 @@ __global__ __launch_bounds__(256, 1) void gru_wide_split_kernel(const float* __r
 
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, n = lane & 15;
-    const long tile = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (tile * kWindowsPerWave >= n_windows) return;
-    const long w_first = tile * kWindowsPerWave + n;             // the lane's windows: w_first and w_first + 16
+    const long tile = (long)blockIdx.x * C::waves + (threadIdx.x >> 6);
+    if (tile * C::wave_windows >= n_windows) return;             // wave-uniform, after the only barrier
+    const long w_first = tile * C::wave_windows + n;             // the lane's windows: w_first (and w_first + 16)
     const long last_row = n_windows + kT - 2;                    // the workspace holds n_windows + 29 rows
     constexpr int kRow = 3 * UT * 32;                            // floats per projected row
     // tile rows 16 mi + 4 q + i of a 32-row image stored per lane half (hh, element): hh = q & 1, elements
     // 4 (2 mi + (q >> 1)) + i, i.e. float offset 16 hh + that
     const int chunk = 16 * split_image_half(q) + split_image_elem(q, 0);            // mi = 0; mi = 1 is 8 floats on
 
-    f32x16 h[UT], lacc, row[3 * UT];
+    WideTile<NI> h[UT], lacc, row[3 * UT];
 #pragma unroll
-    for (int u = 0; u < UT; ++u)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) h[u][i] = 0.0f;
+        for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) lacc[i] = 0.0f;
+            for (int u = 0; u < UT; ++u) h[u].v[mi][ni] = f32x4s{0.0f, 0.0f, 0.0f, 0.0f};
+            lacc.v[mi][ni] = f32x4s{0.0f, 0.0f, 0.0f, 0.0f};
+        }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {                             // step 0: rows w_first and w_first + 16
+    for (int ni = 0; ni < NI; ++ni) {                            // step 0: rows w_first (and w_first + 16)
         const long r0 = w_first + 16 * ni;
         const float* src = gi + (r0 < last_row ? r0 : last_row) * kRow + chunk;
 #pragma unroll
         for (int gm = 0; gm < 3 * UT; ++gm)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const float4 v = *reinterpret_cast<const float4*>(src + gm * 32 + 8 * mi);
-                row[gm][split_index(mi, ni, 0)] = v.x; row[gm][split_index(mi, ni, 1)] = v.y;
-                row[gm][split_index(mi, ni, 2)] = v.z; row[gm][split_index(mi, ni, 3)] = v.w;
-            }
+            for (int mi = 0; mi < 2; ++mi) row[gm].v[mi][ni] = *reinterpret_cast<const f32x4s*>(src + gm * 32 + 8 * mi);
     }
-    WideSplitB<UT> b;
+    WideSplitB<UT, NI> b;
+    float head2[NI][2];                                          // 2-row head: running sums of the lane's rows
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) head2[ni][0] = head2[ni][1] = 0.0f;
 
     for (int t = 0; t < kT; ++t) {
         // the row the wave's last window consumes at the next step
-        const long rn = tile * kWindowsPerWave + 31 + t + 1;
+        const long rn = tile * C::wave_windows + (C::wave_windows - 1) + t + 1;
         const float* nxt = gi + (rn < last_row ? rn : last_row) * kRow + chunk;
         SplitHeadWeights hw[UT];                                 // 2-row head: vector ALU, float32 weights
         if (!LARGE) {
@@ -726,99 +753,110 @@ __global__ __launch_bounds__(256, 1) void gru_wide_split_kernel(const float* __r
         }
 #pragma unroll
         for (int mt = 0; mt < UT; ++mt) {
-            f32x16 acc[4];
+            WideTile<NI> acc[4];
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[g] = row[g * UT + mt];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {                     // b_hn
-                const float4 v = *reinterpret_cast<const float4*>(cb + (3 * UT + mt) * 32 + chunk + 8 * mi);
+                const f32x4s v = *reinterpret_cast<const f32x4s*>(cb + (3 * UT + mt) * 32 + chunk + 8 * mi);
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    acc[3][split_index(mi, ni, 0)] = v.x; acc[3][split_index(mi, ni, 1)] = v.y;
-                    acc[3][split_index(mi, ni, 2)] = v.z; acc[3][split_index(mi, ni, 3)] = v.w;
-                }
+                for (int ni = 0; ni < NI; ++ni) acc[3].v[mi][ni] = v;
             }
             if (t > 0) {
+                // the entries that LDS has no room for (the tail of the last gate's lo terms): requested before the
+                // tile's matrix work, used at its end
+                u32x4 far[2][UT];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int kb = 0; kb < UT; ++kb) {
+                        const int e = kHm + wide_split_base(UT, 2, mt, mi, kb);
+                        if (e >= kLdsEntries) far[mi][kb] = a_glob[e * 64 + lane];
+                    }
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    f32x16& dst = acc[g == 2 ? 3 : g];
+                    WideTile<NI>& dst = acc[g == 2 ? 3 : g];
+                    __builtin_amdgcn_sched_barrier(0);           // one gate's operand reads at a time
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) {
-                        f32x4s c[2];
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) c[ni][i] = dst[split_index(mi, ni, i)];
+                    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                         for (int kb = 0; kb < UT; ++kb) {
                             const int base = wide_split_base(UT, g, mt, mi, kb);
                             const u32x4 ah = a_lds[(base * 2 + 0) * 64 + lane], am = a_lds[(base * 2 + 1) * 64 + lane];
-                            const u32x4 al = g < 2 ? a_lds[(kHm + base) * 64 + lane] : a_glob[(kHm + base) * 64 + lane];
-                            wide_split_terms<UT, TERMS>(c, ah, am, al, b, kb);
+                            const u32x4 al = kHm + base < kLdsEntries ? a_lds[(kHm + base) * 64 + lane] : far[mi][kb];
+                            wide_split_terms<UT, NI, TERMS>(dst.v[mi], ah, am, al, b, kb);
                         }
-#pragma unroll
-                        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) dst[split_index(mi, ni, i)] = c[ni][i];
-                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float r = sigmoid_pre(acc[0][i]);
-                const float z = sigmoid_pre(acc[1][i]);
-                const float nn = tanh_pre(fmaf(r, acc[3][i], acc[2][i]));
-                h[mt][i] = fmaf(z, h[mt][i] - nn, nn);           // in place: the products read the split copy
-            }
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float r = sigmoid_pre(acc[0].v[mi][ni][i]);
+                        const float z = sigmoid_pre(acc[1].v[mi][ni][i]);
+                        const float nn = tanh_pre(fmaf(r, acc[3].v[mi][ni][i], acc[2].v[mi][ni][i]));
+                        h[mt].v[mi][ni][i] = fmaf(z, h[mt].v[mi][ni][i] - nn, nn);   // in place: the products read the split copy
+                    }
             if (t + 1 < kT) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    f32x16& rv = row[g * UT + mt];
+                    WideTile<NI>& rv = row[g * UT + mt];
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            float x0 = rv[split_index(mi, 0, i)], x1 = rv[split_index(mi, 1, i)];
-                            rows_down(x0, x1);
-                            rv[split_index(mi, 0, i)] = x0;
-                            rv[split_index(mi, 1, i)] = x1;
-                        }
+                        for (int i = 0; i < 4; ++i) rows_down<NI>(rv.v[mi], i);
                     if (n == 15) {                               // in flight until the next step
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi) {
-                            const float4 v = *reinterpret_cast<const float4*>(nxt + (g * UT + mt) * 32 + 8 * mi);
-                            rv[split_index(mi, 1, 0)] = v.x; rv[split_index(mi, 1, 1)] = v.y;
-                            rv[split_index(mi, 1, 2)] = v.z; rv[split_index(mi, 1, 3)] = v.w;
-                        }
+                        for (int mi = 0; mi < 2; ++mi)
+                            rv.v[mi][NI - 1] = *reinterpret_cast<const f32x4s*>(nxt + (g * UT + mt) * 32 + 8 * mi);
                     }
                 }
             }
         }
-        wide_split_state<UT>(b, h);                              // for this step's head and the next step's gates
+        wide_split_state<UT, NI>(b, h);                          // for this step's head and the next step's gates
         if (LARGE) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                f32x4s c[2];
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) c[ni][i] = lacc[split_index(mi, ni, i)];
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int kb = 0; kb < UT; ++kb) {
                     const u32x4* e = a_head + (size_t)(((t * 2 + mi) * UT + kb) * 3) * 64 + lane;
-                    wide_split_terms<UT, TERMS>(c, e[0], e[64], e[128], b, kb);
+                    wide_split_terms<UT, NI, TERMS>(lacc.v[mi], e[0], e[64], e[128], b, kb);
                 }
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) lacc[split_index(mi, ni, i)] = c[ni][i];
-            }
         } else {
 #pragma unroll
-            for (int kb = 0; kb < UT; ++kb) split_head_step(lacc, hw[kb], h[kb]);
+            for (int kb = 0; kb < UT; ++kb)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            head2[ni][0] = fmaf(hw[kb].w[4 * mi + i].x, h[kb].v[mi][ni][i], head2[ni][0]);
+                            head2[ni][1] = fmaf(hw[kb].w[4 * mi + i].y, h[kb].v[mi][ni][i], head2[ni][1]);
+                        }
         }
     }
-    split_head_epilogue<LARGE>(lacc, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold);
+    // epilogue in the layout split_head_epilogue reads (element (mi, ni, i) = split_index; 2-row head: elements 2 ni, 2 ni + 1)
+    f32x16 out;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = 0.0f;
+    if (LARGE) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) out[split_index(mi, ni, i)] = lacc.v[mi][ni][i];
+    } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            out[2 * ni] = head2[ni][0];
+            out[2 * ni + 1] = head2[ni][1];
+        }
+    }
+    split_head_epilogue<LARGE, NI>(out, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold);
 }
 
 template <typename K>
@@ -838,11 +876,14 @@ int allow_wide() {
 
 constexpr int wide_split_lds_floats(int ut) { return wide_split_lds_entries(ut) * kSplitEntry + 4 * ut * 32; }
 
+constexpr int kWideSplitNi = 1;       // window halves per lane of gru_wide_split_kernel: 16 windows per wave, two waves per SIMD
+                                      // (2 = 32 windows per wave, one wave per SIMD with all 512 registers: measured 199 vs 148 ms)
+
 template <bool LARGE, int UT>
 int allow_wide_split() {
-    int rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, 9>, wide_split_lds_floats(UT));
+    int rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, 9, kWideSplitNi>, wide_split_lds_floats(UT));
     if (rc != VAD_OK) return rc;
-    return allow_lds(&gru_wide_split_kernel<LARGE, UT, 6>, wide_split_lds_floats(UT));
+    return allow_lds(&gru_wide_split_kernel<LARGE, UT, 6, kWideSplitNi>, wide_split_lds_floats(UT));
 }
 
 }  // namespace
@@ -916,12 +957,16 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
             VAD_REQUIRE(pblocks <= 0x7FFFFFFFL && blocks <= 0x7FFFFFFFL, "too many windows for one launch");
             hipLaunchKernelGGL((row_project_kernel<UT>), dim3((unsigned)pblocks), dim3(256), 0, st, x + w0 * kF, rows, blob,
                                ws.ptr);
+            using SC = WideSplitCfg<kWideSplitNi>;
+            const long sblocks = (nw + SC::waves * SC::wave_windows - 1) / (SC::waves * SC::wave_windows);
             if (matrix_mode == VAD_MATRIX_BF16X9)
-                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 9>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
-                                   split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 9, kWideSplitNi>), dim3((unsigned)sblocks),
+                                   dim3(64 * SC::waves), split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0,
+                                   dec ? dec + w0 : nullptr, mode, threshold);
             else if (matrix_mode == VAD_MATRIX_BF16X6)
-                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 6>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
-                                   split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 6, kWideSplitNi>), dim3((unsigned)sblocks),
+                                   dim3(64 * SC::waves), split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0,
+                                   dec ? dec + w0 : nullptr, mode, threshold);
             else
                 hipLaunchKernelGGL((gru_wide_stream_kernel<LARGE, UT, KL>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
                                    lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);

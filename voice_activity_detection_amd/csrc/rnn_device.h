@@ -41,10 +41,14 @@ constexpr int kSplitEntry = 64 * 4;          // dwords of one bf16 A operand of 
 
 // GRU with ut > 1 unit tiles: the split recurrent operands are entries (gate g, unit tile mt, row half mi, k-block kb,
 // term) in two sections, first hi and mid of everything, then the lo terms gate by gate (r, z, n): the wide split
-// kernel keeps everything but the last gate's lo terms in LDS.
+// kernel keeps the leading wide_split_lds_entries of them in LDS.
 __host__ __device__ constexpr int wide_split_hm_entries(int ut) { return 3 * ut * 2 * ut * 2; }
 __host__ __device__ constexpr int wide_split_gate_entries(int ut) { return 3 * ut * 2 * ut * 3; }
-__host__ __device__ constexpr int wide_split_lds_entries(int ut) { return wide_split_hm_entries(ut) + 2 * ut * 2 * ut; }
+// 158 entries of 1 KB and the biases are what 160 KB of LDS take: for three unit tiles all but the last four lo
+// entries of the last gate (read from the weight blob instead)
+__host__ __device__ constexpr int wide_split_lds_entries(int ut) {
+    return wide_split_gate_entries(ut) < 158 ? wide_split_gate_entries(ut) : 158;
+}
 __host__ __device__ constexpr int wide_split_base(int ut, int g, int mt, int mi, int kb) {
     return (((g * ut + mt) * 2 + mi) * ut + kb);
 }
@@ -363,13 +367,13 @@ __device__ __forceinline__ float sum_over_q(float x) {          // over the four
 
 // (ReLU, lin2) or the bias of lin; softmax over the 2 classes; decision.  Window half ni of lane 16 q + n is
 // window w_first + 16 ni; the lanes with q = 0 store.
-template <bool LARGE>
+template <bool LARGE, int NI = 2>
 __device__ __forceinline__ void split_head_epilogue(const f32x16& lacc, const float* __restrict__ tail, int lane, long w_first,
                                                     long n_windows, float* __restrict__ p_out, uint8_t* __restrict__ dec_out,
                                                     int mode, float threshold) {
     const int q = lane >> 4;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
         float l0 = 0.0f, l1 = 0.0f;
         if (LARGE) {
             const int hh = split_image_half(q);
