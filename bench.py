@@ -78,27 +78,40 @@ MODEL_KERNEL = {'gru_large': 'rnn_stream_kernel<false, true, 15>', 'gru_small': 
                 'densenet': 'densenet_stream_kernel<false>', 'densenet_large': 'densenet_stream_kernel<true>'}
 
 
+HIDDEN = {'gru_h90': 90}                     # every other recurrent model has the reference's 30 units
+
+
+def split_mode_applies(model):
+    """The bf16 split matrix modes apply to the stride-1 GRU / LSTM kernels (30 units, and the wide GRU's
+    workspace path); DenseNet always computes on the float32 MFMA."""
+    return not MODEL_KERNEL[model].startswith('densenet')
+
+
 def model_peak(model, mode):
     """The float32 flop rate the hardware could sustain on a model's algorithmic work.  float32 MFMA and float32
-    vector work share one pipe (157.3 TF).  In the bf16 split modes of the 30-unit GRU / LSTM the recurrent and
-    26-row head products run as 9 (or 6) bf16 partial products each on the bf16 matrix pipe, beside the rest of
-    the work (projection, gate math, 2-row head) on the float32 pipe: the slower of the two pipes bounds it."""
-    if mode == 'f32' or not MODEL_KERNEL[model].startswith('rnn_stream_kernel'):
+    vector work share one pipe (157.3 TF).  In the bf16 split modes the recurrent and 26-row head products run as
+    9 (or 6) bf16 partial products each on the bf16 matrix pipe, beside the rest of the work (projection, gate
+    math, 2-row head) on the float32 pipe: the slower of the two pipes bounds it."""
+    if mode == 'f32' or not split_mode_applies(model):
         return PEAK_FP32_TFLOPS
     gates = 4 if model.startswith('lstm') else 3
-    head_rows = 26 if model.endswith('large') else 0            # the 2-row head stays on the vector ALU
+    hidden = HIDDEN.get(model, 30)
+    head_rows = 2 if model.endswith('small') else 26            # the 2-row head stays on the vector ALU
     total = FLOP_PER_WINDOW[model][0]
-    on_bf16 = T * (30 * gates * 30 * 2 + 30 * head_rows * 2)
+    on_bf16 = T * (hidden * gates * hidden * 2 + (hidden * head_rows * 2 if head_rows == 26 else 0))
     seconds = max(on_bf16 * int(mode[-1]) / (PEAK_BF16_TFLOPS * 1e12), (total - on_bf16) / (PEAK_FP32_TFLOPS * 1e12))
     return total / seconds / 1e12
 
 
 def model_kernel(model, mode):
-    """Kernel name for a model under a matrix mode: the bf16 split modes apply to the 30-unit GRU / LSTM only."""
+    """Kernel name for a model under a matrix mode, as rocprofv3 prints it."""
     name = MODEL_KERNEL[model]
     if mode != 'f32' and name.startswith('rnn_stream_kernel'):
         lstm, large = name[name.index('<') + 1:].split(', ')[:2]
         return 'rnn_stream_split_kernel<%s, %s, %s>' % (lstm, large, mode[-1])
+    if mode != 'f32' and name.startswith('gru_wide_stream_kernel'):
+        large, ut = name[name.index('<') + 1:].split(', ')[:2]
+        return 'gru_wide_split_kernel<%s, %s, %s, 1>' % (large, ut, mode[-1])
     return name
 
 

@@ -34,6 +34,9 @@
 //                      (bias + W_ih x, the same fmaf chain) into LDS and the steps start their
 //                      accumulators from there (64 MFMAs per GRU step).  Results are bit-identical
 //                      to rnn_kernel.
+// rnn_stream_split_kernel and gru_wide_split_kernel are the stride-1 kernels with the recurrent and head products
+// on the bf16 matrix pipe (float32 operands split exactly into three bf16); the gru_wide_* kernels take GRUs with
+// 33..96 hidden units.
 
 #include <math.h>
 #include <string.h>

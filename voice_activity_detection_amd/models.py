@@ -23,7 +23,8 @@ MATRIX_MODES = {'f32': 0, 'bf16x6': 1, 'bf16x9': 2}
 
 
 def set_matrix_mode(mode):
-    """Process-wide: how the stride-1 GRU / LSTM kernels form their float32 matrix products.
+    """Process-wide: how the stride-1 GRU / LSTM kernels (and the wide GRU's stride-1 workspace path) form their
+    float32 matrix products.
     'bf16x9' (default) splits every float32 operand exactly into three bfloat16 and accumulates all nine exact
     partial products in float32 on the bf16 matrix pipe; 'f32' is the float32 MFMA (a k-ordered FMA chain,
     bit-identical to the dense-batch and sampled-window paths); 'bf16x6' drops the three smallest partial
