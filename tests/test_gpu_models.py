@@ -98,7 +98,7 @@ def test_fixture_through_the_stride1_kernels(vad, golden_dir, kind):
         assert np.abs(got - y).max() <= ATOL, (mode, np.abs(got - y).max())
 
 
-@pytest.mark.parametrize('kind', ['gru_large', 'lstm_small', 'densenet'])
+@pytest.mark.parametrize('kind', ['gru_large', 'lstm_small', 'densenet', 'densenet_large'])
 def test_sliding_windows_equal_explicit_windows(vad, kind, f32_matrix_mode):
     """Stride-1 windows read in place from the (F,24) matrix give the same bits as a
     materialised (B,30,24) batch (GRU / LSTM: in the float32-MFMA matrix mode), and both match the

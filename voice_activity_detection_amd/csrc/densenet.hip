@@ -123,9 +123,15 @@ struct ActView {
     }
 };
 
-// One dense block: NL growth layers over L positions, appended channel by channel.
-template <int NL, int G, int L>
-__device__ __forceinline__ void dense_block(const ActView& v, const float* block_w, int c_first, int half) {
+// One dense block: NL growth layers over L positions, appended channel by channel.  The outputs of layers
+// REG_FROM.. stay in registers instead of LDS: the lane halves split the input channels by parity, so a growth
+// channel is only ever read by one half, and gr[s][l] holds relative channel G REG_FROM + 2 s + half at position l
+// (G even when REG_FROM < NL).  With REG_FROM = NL everything goes to LDS.
+template <int NL, int G, int L, int REG_FROM>
+__device__ __forceinline__ void dense_block(const ActView& v, const float* block_w, int c_first, int half,
+                                            float (&gr)[(NL - REG_FROM) * G / 2 + 1][L]) {
+    static_assert(REG_FROM == NL || G % 2 == 0, "register-resident growth channels pair up by parity");
+    constexpr int kRegFirst = G * REG_FROM;                       // first relative channel kept in registers
 #pragma unroll
     for (int layer = 0; layer < NL; ++layer) {                    // unrolled: the channel count below is a constant
         const int cin = c_first + G * layer;
@@ -135,10 +141,7 @@ __device__ __forceinline__ void dense_block(const ActView& v, const float* block
         for (int o = 0; o < G; ++o)
 #pragma unroll
             for (int l = 0; l < L; ++l) acc[o][l] = 0.0f;
-        auto channel = [&](int c, const float* src, int sl) {
-            float a[L];
-#pragma unroll
-            for (int l = 0; l < L; ++l) a[l] = src[l * sl];
+        auto accumulate = [&](int c, const float (&a)[L]) {
             const float4* wp = reinterpret_cast<const float4*>(wl + c * 12);
             const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
             const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
@@ -152,24 +155,46 @@ __device__ __forceinline__ void dense_block(const ActView& v, const float* block
                     acc[o][l] = s;
                 }
         };
+        auto channel = [&](int c, const float* src, int sl) {
+            float a[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) a[l] = src[l * sl];
+            accumulate(c, a);
+        };
         // The lane halves take the even / the odd channels (c_first is even, so both halves leave the first
         // range together).  A wave is nearly alone on its SIMD (LDS-bound occupancy), so the weight loads
         // of several channels have to be in flight at once: the unrolled iterations are independent until
         // the accumulation.
 #pragma unroll 4
         for (int c = half; c < c_first; c += 2) channel(c, v.a + c * v.a_c, v.a_l);
+        const int lds_end = layer < REG_FROM ? cin : c_first + kRegFirst;   // growth channels that live in LDS
 #pragma unroll 4
-        for (int c = c_first + half; c < cin; c += 2) channel(c, v.b + (c - c_first) * v.b_c, v.b_l);
+        for (int c = c_first + half; c < lds_end; c += 2) channel(c, v.b + (c - c_first) * v.b_c, v.b_l);
+        if (layer > REG_FROM) {
+#pragma unroll
+            for (int s2 = 0; s2 < (layer - REG_FROM) * G / 2; ++s2) accumulate(c_first + kRegFirst + 2 * s2 + half, gr[s2]);
+        }
         const float4 sh4 = *reinterpret_cast<const float4*>(wl + cin * 12);
         const float sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        if (layer < REG_FROM) {
 #pragma unroll
-        for (int o = 0; o < G; ++o)
+            for (int o = 0; o < G; ++o)
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const float y = lrelu(sum_across_halves(acc[o][l]) + sh[o]);
-                if (half == 0) v.b[(cin + o - c_first) * v.b_c + l * v.b_l] = y;
-            }
-        wave_lds_fence();
+                for (int l = 0; l < L; ++l) {
+                    const float y = lrelu(sum_across_halves(acc[o][l]) + sh[o]);
+                    if (half == 0) v.b[(cin + o - c_first) * v.b_c + l * v.b_l] = y;
+                }
+            wave_lds_fence();
+        } else if constexpr (REG_FROM < NL) {
+#pragma unroll
+            for (int o = 0; o < G; o += 2)
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const float y0 = lrelu(sum_across_halves(acc[o][l]) + sh[o]);
+                    const float y1 = lrelu(sum_across_halves(acc[o + 1][l]) + sh[o + 1]);
+                    gr[((layer - REG_FROM) * G + o) / 2][l] = half ? y1 : y0;
+                }
+        }
     }
 }
 
@@ -210,7 +235,8 @@ __device__ __forceinline__ void stem_pair(const float* xe_row, const float* __re
 // Everything after the stem for a wave's 32 windows: dense block 1 over `v1`, transition into the plain
 // private array act2[c][2][32] (which may alias v1's growth region), dense block 2, cnn_out, Linear, softmax.
 // `dense_w[b]` points at the growth-layer weights of dense block b (the blob's, or a copy in LDS).
-template <bool LARGE>
+// REG1 / REG2: first growth layer of dense block 1 / 2 whose outputs stay in registers (D::nl = none).
+template <bool LARGE, int REG1 = Dims<LARGE>::nl, int REG2 = Dims<LARGE>::nl>
 __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, const float* __restrict__ blob,
                                               const float* dense_w0, const float* dense_w1,
                                               const DnLayout& LY, int lane, long w, long n_windows,
@@ -220,7 +246,9 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
     const int half = lane >> 5, col = lane & 31;
 
     // ---- dense block 1 (5 positions) ----
-    dense_block<D::nl, D::g, kL1>(v1, dense_w0, D::c0, half);
+    float gr1[(D::nl - REG1) * D::g / 2 + 1][kL1];
+    dense_block<D::nl, D::g, kL1, REG1>(v1, dense_w0, D::c0, half, gr1);
+    constexpr int kSReg1 = (D::c0 + D::g * REG1) / 2;           // first k-step of the 1x1 convolution fed from gr1
 
     // ---- transition: 1x1 conv c1 -> c0 + BN + MaxPool(2) + LeakyReLU, 5 -> 2 (position 4 is dropped) ----
     f32x16 tr[D::mt0][kL2];
@@ -230,7 +258,7 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
 #pragma unroll
         for (int mt = 0; mt < D::mt0; ++mt) acc_e[mt] = acc_o[mt] = load_shift(blob + LY.s_tr + mt * 32, half);
 #pragma unroll 8
-        for (int s = 0; s < D::ks1; ++s) {
+        for (int s = 0; s < kSReg1; ++s) {
             const int c = 2 * s + half;
             const float be = v1.ld(c, 2 * lp);
             const float bo = v1.ld(c, 2 * lp + 1);
@@ -239,6 +267,15 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
                 const float a = blob[LY.a_tr + (mt * D::ks1 + s) * 64 + lane];
                 acc_e[mt] = MFMA(a, be, acc_e[mt]);
                 acc_o[mt] = MFMA(a, bo, acc_o[mt]);
+            }
+        }
+#pragma unroll
+        for (int s = kSReg1; s < D::ks1; ++s) {                  // channels 2 s + half live in registers
+#pragma unroll
+            for (int mt = 0; mt < D::mt0; ++mt) {
+                const float a = blob[LY.a_tr + (mt * D::ks1 + s) * 64 + lane];
+                acc_e[mt] = MFMA(a, gr1[s - kSReg1][2 * lp], acc_e[mt]);
+                acc_o[mt] = MFMA(a, gr1[s - kSReg1][2 * lp + 1], acc_o[mt]);
             }
         }
 #pragma unroll
@@ -260,7 +297,9 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
 
     // ---- dense block 2 (2 positions) ----
     const ActView v2{act2 + col, kL2 * 32, 32, act2 + D::c0 * kL2 * 32 + col, kL2 * 32, 32, D::c0};
-    dense_block<D::nl, D::g, kL2>(v2, dense_w1, D::c0, half);
+    float gr2[(D::nl - REG2) * D::g / 2 + 1][kL2];
+    dense_block<D::nl, D::g, kL2, REG2>(v2, dense_w1, D::c0, half, gr2);
+    constexpr int kSReg2 = (D::c0 + D::g * REG2) / 2;
 
     // ---- cnn_out: 1x1 conv c1 -> c1 + BN + MaxPool(2) + LeakyReLU, 2 -> 1; then Linear(c1 -> 2) ----
     float l0 = 0.0f, l1 = 0.0f;
@@ -269,11 +308,17 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
         f32x16 acc_e, acc_o;
         acc_e = acc_o = load_shift(blob + LY.s_out + mt * 32, half);
 #pragma unroll 8
-        for (int s = 0; s < D::ks1; ++s) {
+        for (int s = 0; s < kSReg2; ++s) {
             const int c = 2 * s + half;
             const float a = blob[LY.a_out + (mt * D::ks1 + s) * 64 + lane];
             acc_e = MFMA(a, act2[(c * kL2 + 0) * 32 + col], acc_e);
             acc_o = MFMA(a, act2[(c * kL2 + 1) * 32 + col], acc_o);
+        }
+#pragma unroll
+        for (int s = kSReg2; s < D::ks1; ++s) {
+            const float a = blob[LY.a_out + (mt * D::ks1 + s) * 64 + lane];
+            acc_e = MFMA(a, gr2[s - kSReg2][0], acc_e);
+            acc_o = MFMA(a, gr2[s - kSReg2][1], acc_o);
         }
         const float* wf0 = blob + LY.w_fin + ((mt * 2 + 0) * 2 + half) * 16;
         const float* wf1 = blob + LY.w_fin + ((mt * 2 + 1) * 2 + half) * 16;
@@ -327,16 +372,19 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
 // Stride-1 windows over a packed (F, 24) matrix.  The stem output at pooled position lp of window w is
 // M[w + 2 lp], M[r] = LeakyReLU(max(S[r], S[r + 1])) with S[r] the stem convolution at absolute row r:
 // it belongs to the row, not to the window, and ten overlapping windows would each recompute it.  A block
-// of NW waves computes M once for its NW * 32 rows (one 32-row tile per wave) into a shared LDS image and
+// of NW = 8 waves computes M once for its NW * 32 rows (one 32-row tile per wave) into a shared LDS image and
 // then scores its NW * 32 - 8 windows from it; only the growth channels are private to a wave.
 template <bool LARGE>
 struct DnStreamCfg {
     using D = Dims<LARGE>;
-    static constexpr int waves = LARGE ? 6 : 8;
+    static constexpr int waves = 8;
     static constexpr int rows = waves * 32;                      // M rows per block
     static constexpr int windows = rows - 8;                     // window w reads M[w .. w + 8]
-    static constexpr int grow = D::nl * D::g;                    // growth channels of a dense block
-    static constexpr int priv1 = grow * kL1 * 32, priv2 = D::c1 * kL2 * 32;
+    // The large model keeps the growth channels of block 1's last three layers and all of block 2's in registers:
+    // 12.8 KB of private activations per wave instead of 20 KB, which is what lets 8 waves (two per SIMD) share a CU.
+    static constexpr int reg1 = LARGE ? D::nl - 3 : D::nl;       // first register-resident growth layer, block 1
+    static constexpr int reg2 = LARGE ? 0 : D::nl;               //                                       block 2
+    static constexpr int priv1 = reg1 * D::g * kL1 * 32, priv2 = (D::c0 + reg2 * D::g) * kL2 * 32;
     static constexpr int priv = priv1 > priv2 ? priv1 : priv2;   // per wave: block-1 growth channels, then all of block 2
     // The growth-layer weights of both dense blocks are read once per channel by every wave, two addresses
     // per wave-instruction: the small model keeps a block-shared copy in LDS (the large model's LDS is full).
@@ -389,7 +437,7 @@ __global__ __launch_bounds__(DnStreamCfg<LARGE>::waves * 64) void densenet_strea
     const ActView v1{M + ml, C::rows, 2, priv + col, kL1 * 32, 32, D::c0};
     const float* dw0 = C::dense_in_lds ? dense_lds : blob + LY.dense[0];
     const float* dw1 = C::dense_in_lds ? dense_lds + dense_layer_offset(D::c0, D::g, D::nl) : blob + LY.dense[1];
-    densenet_tail<LARGE>(v1, priv, blob, dw0, dw1, LY, lane, w, n_windows, p_out, dec_out, mode, threshold);
+    densenet_tail<LARGE, C::reg1, C::reg2>(v1, priv, blob, dw0, dw1, LY, lane, w, n_windows, p_out, dec_out, mode, threshold);
 }
 
 // ---------------------------------------------------------------------------------------------
