@@ -126,12 +126,18 @@ struct ActView {
 // One dense block: NL growth layers over L positions, appended channel by channel.  The outputs of layers
 // REG_FROM.. stay in registers instead of LDS: the lane halves split the input channels by parity, so a growth
 // channel is only ever read by one half, and gr[s][l] holds relative channel G REG_FROM + 2 s + half at position l
-// (G even when REG_FROM < NL).  With REG_FROM = NL everything goes to LDS.
+// (G REG_FROM even).  With REG_FROM = NL everything goes to LDS.
 template <int NL, int G, int L, int REG_FROM>
 __device__ __forceinline__ void dense_block(const ActView& v, const float* block_w, int c_first, int half,
-                                            float (&gr)[(NL - REG_FROM) * G / 2 + 1][L]) {
-    static_assert(REG_FROM == NL || G % 2 == 0, "register-resident growth channels pair up by parity");
+                                            float (&gr)[((NL - REG_FROM) * G + 1) / 2 + 1][L]) {
+    static_assert((G * REG_FROM) % 2 == 0, "the register-resident channels start at an even channel");
     constexpr int kRegFirst = G * REG_FROM;                       // first relative channel kept in registers
+    if constexpr (REG_FROM < NL) {
+#pragma unroll
+        for (int s2 = 0; s2 < ((NL - REG_FROM) * G + 1) / 2; ++s2)
+#pragma unroll
+            for (int l = 0; l < L; ++l) gr[s2][l] = 0.0f;
+    }
 #pragma unroll
     for (int layer = 0; layer < NL; ++layer) {                    // unrolled: the channel count below is a constant
         const int cin = c_first + G * layer;
@@ -162,17 +168,28 @@ __device__ __forceinline__ void dense_block(const ActView& v, const float* block
             accumulate(c, a);
         };
         // The lane halves take the even / the odd channels (c_first is even, so both halves leave the first
-        // range together).  A wave is nearly alone on its SIMD (LDS-bound occupancy), so the weight loads
-        // of several channels have to be in flight at once: the unrolled iterations are independent until
-        // the accumulation.
+        // range together).  The weight loads of several channels have to be in flight at once: the unrolled
+        // iterations are independent until the accumulation.
 #pragma unroll 4
         for (int c = half; c < c_first; c += 2) channel(c, v.a + c * v.a_c, v.a_l);
         const int lds_end = layer < REG_FROM ? cin : c_first + kRegFirst;   // growth channels that live in LDS
 #pragma unroll 4
         for (int c = c_first + half; c < lds_end; c += 2) channel(c, v.b + (c - c_first) * v.b_c, v.b_l);
-        if (layer > REG_FROM) {
+        if constexpr (REG_FROM < NL) {
+            const int n_reg = layer > REG_FROM ? (layer - REG_FROM) * G : 0;     // register-resident inputs of this layer
 #pragma unroll
-            for (int s2 = 0; s2 < (layer - REG_FROM) * G / 2; ++s2) accumulate(c_first + kRegFirst + 2 * s2 + half, gr[s2]);
+            for (int s2 = 0; s2 < (n_reg + 1) / 2; ++s2) {
+                if (2 * s2 + 1 < n_reg) {
+                    accumulate(c_first + kRegFirst + 2 * s2 + half, gr[s2]);
+                } else {
+                    // the odd channel of the last pair does not exist yet: the upper half multiplies zeros (by the
+                    // rows that follow in the weight table: finite values)
+                    float a[L];
+#pragma unroll
+                    for (int l = 0; l < L; ++l) a[l] = half ? 0.0f : gr[s2][l];
+                    accumulate(c_first + kRegFirst + 2 * s2 + half, a);
+                }
+            }
         }
         const float4 sh4 = *reinterpret_cast<const float4*>(wl + cin * 12);
         const float sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
@@ -187,13 +204,14 @@ __device__ __forceinline__ void dense_block(const ActView& v, const float* block
             wave_lds_fence();
         } else if constexpr (REG_FROM < NL) {
 #pragma unroll
-            for (int o = 0; o < G; o += 2)
+            for (int o = 0; o < G; ++o) {
+                const int rel = (layer - REG_FROM) * G + o;      // relative to the first register-resident channel
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    const float y0 = lrelu(sum_across_halves(acc[o][l]) + sh[o]);
-                    const float y1 = lrelu(sum_across_halves(acc[o + 1][l]) + sh[o + 1]);
-                    gr[((layer - REG_FROM) * G + o) / 2][l] = half ? y1 : y0;
+                    const float y = lrelu(sum_across_halves(acc[o][l]) + sh[o]);
+                    gr[rel / 2][l] = (half == (rel & 1)) ? y : gr[rel / 2][l];
                 }
+            }
         }
     }
 }
@@ -246,7 +264,7 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
     const int half = lane >> 5, col = lane & 31;
 
     // ---- dense block 1 (5 positions) ----
-    float gr1[(D::nl - REG1) * D::g / 2 + 1][kL1];
+    float gr1[((D::nl - REG1) * D::g + 1) / 2 + 1][kL1];
     dense_block<D::nl, D::g, kL1, REG1>(v1, dense_w0, D::c0, half, gr1);
     constexpr int kSReg1 = (D::c0 + D::g * REG1) / 2;           // first k-step of the 1x1 convolution fed from gr1
 
@@ -297,7 +315,7 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
 
     // ---- dense block 2 (2 positions) ----
     const ActView v2{act2 + col, kL2 * 32, 32, act2 + D::c0 * kL2 * 32 + col, kL2 * 32, 32, D::c0};
-    float gr2[(D::nl - REG2) * D::g / 2 + 1][kL2];
+    float gr2[((D::nl - REG2) * D::g + 1) / 2 + 1][kL2];
     dense_block<D::nl, D::g, kL2, REG2>(v2, dense_w1, D::c0, half, gr2);
     constexpr int kSReg2 = (D::c0 + D::g * REG2) / 2;
 
@@ -377,19 +395,22 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
 template <bool LARGE>
 struct DnStreamCfg {
     using D = Dims<LARGE>;
-    static constexpr int waves = 8;
+    static constexpr int waves = LARGE ? 8 : 12;
     static constexpr int rows = waves * 32;                      // M rows per block
     static constexpr int windows = rows - 8;                     // window w reads M[w .. w + 8]
-    // The large model keeps the growth channels of block 1's last three layers and all of block 2's in registers:
-    // 12.8 KB of private activations per wave instead of 20 KB, which is what lets 8 waves (two per SIMD) share a CU.
-    static constexpr int reg1 = LARGE ? D::nl - 3 : D::nl;       // first register-resident growth layer, block 1
-    static constexpr int reg2 = LARGE ? 0 : D::nl;               //                                       block 2
+    // Growth channels kept in registers instead of LDS (dense_block): the small model all of them (63 registers;
+    // 6 KB of private LDS per wave, 12 waves = three per SIMD share a CU), the large model those of block 1's last
+    // three layers and all of block 2's (12.8 KB instead of 20 KB per wave, 8 waves = two per SIMD; more would
+    // not fit its 256 registers).
+    static constexpr int reg1 = LARGE ? D::nl - 3 : 0;           // first register-resident growth layer, block 1
+    static constexpr int reg2 = 0;                               //                                       block 2
     static constexpr int priv1 = reg1 * D::g * kL1 * 32, priv2 = (D::c0 + reg2 * D::g) * kL2 * 32;
     static constexpr int priv = priv1 > priv2 ? priv1 : priv2;   // per wave: block-1 growth channels, then all of block 2
     // The growth-layer weights of both dense blocks are read once per channel by every wave, two addresses
     // per wave-instruction: the small model keeps a block-shared copy in LDS (the large model's LDS is full).
     static constexpr bool dense_in_lds = !LARGE;
-    static constexpr int dense_floats = dense_in_lds ? 2 * dense_layer_offset(D::c0, D::g, D::nl) : 0;
+    // (+ 16 floats: a layer whose register-resident inputs end on an even channel reads one row past its weights)
+    static constexpr int dense_floats = dense_in_lds ? 2 * dense_layer_offset(D::c0, D::g, D::nl) + 16 : 0;
     static constexpr int lds_floats = D::c0 * rows + waves * priv + dense_floats;
 };
 
