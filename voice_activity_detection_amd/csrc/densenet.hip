@@ -44,6 +44,13 @@ struct Dims {
     static constexpr int mt0 = (c0 + 31) / 32;       // 32-row tiles covering c0
     static constexpr int mt1 = (c1 + 31) / 32;       // 32-row tiles covering c1
     static constexpr int ks1 = c1 / 2;               // k-steps of a 1x1 convolution over c1 channels
+    // Growth channels kept in registers instead of LDS (dense_block): the small model all of them (63 registers),
+    // the large model those of block 1's last three layers and all of block 2's (more would not fit 256 registers).
+    static constexpr int reg1 = LARGE ? nl - 3 : 0;  // first register-resident growth layer of dense block 1
+    static constexpr int reg2 = 0;                   //                                         of dense block 2
+    // private LDS floats of a wave's 32 windows: block 1's LDS-resident growth channels, then block 2's inputs
+    static constexpr int priv1 = reg1 * g * 5 * 32, priv2 = (c0 + reg2 * g) * 2 * 32;
+    static constexpr int priv = priv1 > priv2 ? priv1 : priv2;
 };
 
 // Blob layout in floats.
@@ -365,7 +372,10 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
                                                       const float* __restrict__ blob, float* __restrict__ p_out,
                                                       uint8_t* __restrict__ dec_out, int mode, float threshold) {
     using D = Dims<LARGE>;
-    __shared__ __align__(16) float act[D::c1 * kL1 * 32];
+    // the stem output [c0][5][32], then block 1's LDS-resident growth channels; block 2's inputs reuse the start
+    constexpr int kStem = D::c0 * kL1 * 32;
+    static_assert(D::priv2 <= kStem + D::priv1, "block 2's inputs fit the region block 1 leaves");
+    __shared__ __align__(16) float act[kStem + D::priv1];
     const DnLayout LY = dn_layout<LARGE>();
     const int lane = threadIdx.x;
     const int half = lane >> 5;
@@ -383,8 +393,8 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
     wave_lds_fence();
 
     const ActView v1{act + col, kL1 * 32, 32, act + D::c0 * kL1 * 32 + col, kL1 * 32, 32, D::c0};
-    densenet_tail<LARGE>(v1, act, blob, blob + LY.dense[0], blob + LY.dense[1], LY, lane, w, n_windows, p_out, dec_out,
-                         mode, threshold);
+    densenet_tail<LARGE, D::reg1, D::reg2>(v1, act, blob, blob + LY.dense[0], blob + LY.dense[1], LY, lane, w, n_windows,
+                                           p_out, dec_out, mode, threshold);
 }
 
 // Stride-1 windows over a packed (F, 24) matrix.  The stem output at pooled position lp of window w is
@@ -398,14 +408,9 @@ struct DnStreamCfg {
     static constexpr int waves = LARGE ? 8 : 12;
     static constexpr int rows = waves * 32;                      // M rows per block
     static constexpr int windows = rows - 8;                     // window w reads M[w .. w + 8]
-    // Growth channels kept in registers instead of LDS (dense_block): the small model all of them (63 registers;
-    // 6 KB of private LDS per wave, 12 waves = three per SIMD share a CU), the large model those of block 1's last
-    // three layers and all of block 2's (12.8 KB instead of 20 KB per wave, 8 waves = two per SIMD; more would
-    // not fit its 256 registers).
-    static constexpr int reg1 = LARGE ? D::nl - 3 : 0;           // first register-resident growth layer, block 1
-    static constexpr int reg2 = 0;                               //                                       block 2
-    static constexpr int priv1 = reg1 * D::g * kL1 * 32, priv2 = (D::c0 + reg2 * D::g) * kL2 * 32;
-    static constexpr int priv = priv1 > priv2 ? priv1 : priv2;   // per wave: block-1 growth channels, then all of block 2
+    // 6 KB (small) / 12.8 KB (large) of private LDS per wave: 12 waves = three per SIMD (small), 8 waves = two per
+    // SIMD (large) share a CU
+    static constexpr int reg1 = D::reg1, reg2 = D::reg2, priv = D::priv;
     // The growth-layer weights of both dense blocks are read once per channel by every wave, two addresses
     // per wave-instruction: the small model keeps a block-shared copy in LDS (the large model's LDS is full).
     static constexpr bool dense_in_lds = !LARGE;
