@@ -353,7 +353,7 @@ def test_split_bf16_matrix_modes(vad, kind, mode):
 
 @pytest.mark.parametrize('kind', ['gru_large', 'gru_small', 'lstm_large', 'lstm_small'])
 def test_split_kernels_at_ragged_window_counts(vad, kind):
-    """Window counts around the kernels' 16-window halves, 32-window waves and 224 / 256-window blocks: every
+    """Window counts around the kernels' 16-window halves, 32-window waves and 192 / 256-window blocks: every
     window scored once, within the bar of the oracle, and nothing written past the last window."""
     ref = models_ref.make_model(kind)
     net = _gpu_model(vad, kind, ref)
@@ -365,7 +365,7 @@ def test_split_kernels_at_ragged_window_counts(vad, kind):
         y = ref(windows).numpy()
     prev = vad.set_matrix_mode('bf16x9')
     try:
-        for n in (1, 15, 16, 17, 31, 32, 33, 223, 224, 225, 255, 256, 257, 571):
+        for n in (1, 15, 16, 17, 31, 32, 33, 191, 192, 193, 255, 256, 257, 571):
             p = torch.full((n + 3, 2), -7.0, device='cuda')
             d = torch.full((n + 3,), 9, dtype=torch.uint8, device='cuda')
             net.score(feat[:n + 29], window_stride=24, n_windows=n, out=p[:n], decisions=d[:n])

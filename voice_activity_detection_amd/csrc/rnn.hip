@@ -46,6 +46,7 @@
 
 #include "rnn_device.h"
 
+
 namespace vad {
 
 using namespace rnn;
@@ -215,12 +216,19 @@ __global__ __launch_bounds__(StreamCfg<LSTM>::waves * 64) void rnn_stream_kernel
 // (float32 operands split exactly into three bf16, TERMS partial products per product; rnn_device.h).
 // The input projection (1/30 of the matrix work) stays on the float32 MFMA.
 
+// ni = window halves per lane.  GRU: 2, a wave owns 32 windows and 8 waves (two per SIMD) share a block's 256 windows.
+// LSTM: 1, 16 windows per wave and 12 waves (three per SIMD) on 192 windows: its step is bound by vector
+// instructions (10 transcendentals per unit), which a third wave per SIMD keeps issuing (measured: LSTM-small 25.0 ->
+// 22.3 ms per 100 h; the GRU loses with that shape, 17.8 -> 18.4, and both lose with 16 waves of 128 registers).
 template <bool LSTM>
 struct SplitCfg {
     static constexpr int G = LSTM ? 4 : 3;
-    static constexpr int waves = LSTM ? 7 : 8;
-    static constexpr int windows = waves * kWindowsPerWave;
-    static constexpr int tiles = waves + 1;
+    static constexpr int ni = LSTM ? 1 : 2;
+    static constexpr int tiles32 = LSTM ? 6 : 8;                 // 32-window groups per block
+    static constexpr int waves = tiles32 * 2 / ni;
+    static constexpr int wave_windows = 16 * ni;
+    static constexpr int windows = tiles32 * 32;
+    static constexpr int tiles = tiles32 + 1;
     // Row stride of the projections in floats.  A 16-byte read of the steps takes rows n = 0..15 from lanes with
     // q = 0 or 1 (4 floats apart): with rs / 4 = 2 (mod 16) the sixteen lanes of a read group fall on distinct
     // banks (GRU, 104).  The LSTM's LDS has no room for the next such stride (136): 132 leaves one 2-way pair.
@@ -273,16 +281,17 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
     // 16 q + n holds tile rows 16 mi + 4 q + i of windows n and 16 + n.  A wave alternates between a matrix phase
     // (24 or 36 bf16 MFMAs of 16 cycles per tile) and a vector phase (gate math, bf16 split); the two waves that
     // share a SIMD (w and w + 4) overlap while they are in different phases. ----
-    if (w0 + wave * kWindowsPerWave >= n_windows) return;       // wave-uniform, after the only barrier
+    constexpr int NI = C::ni;
+    if (w0 + wave * C::wave_windows >= n_windows) return;       // wave-uniform, after the only barrier
     const int q = lane >> 4, n = lane & 15;
-    const long w_first = w0 + wave * kWindowsPerWave + n;        // the lane's windows: w_first and w_first + 16
+    const long w_first = w0 + wave * C::wave_windows + n;        // the lane's windows: w_first (and w_first + 16)
     const float* a1 = blob + L.head;
     const u32x4* s_gate = reinterpret_cast<const u32x4*>(s_hh);
     const u32x4* s_head = reinterpret_cast<const u32x4*>(blob + L.s_head);
     f32x16 h, c, lacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { h[i] = 0.0f; c[i] = 0.0f; lacc[i] = 0.0f; }
-    const float* girow = gi + (wave * kWindowsPerWave + n) * C::rs + 4 * q;
+    const float* girow = gi + (wave * C::wave_windows + n) * C::rs + 4 * q;
     const float* cb_n = cb + (3 * 2 + split_image_half(q)) * 16;             // b_hn of the lane's rows
     SplitB b;
 
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < NI; ++ni) {
                     const float4 v = *reinterpret_cast<const float4*>(girow + (16 * ni + t) * C::rs + g * 32 + 16 * mi);
                     acc[g][split_index(mi, ni, 0)] = v.x; acc[g][split_index(mi, ni, 1)] = v.y;
                     acc[g][split_index(mi, ni, 2)] = v.z; acc[g][split_index(mi, ni, 3)] = v.w;
@@ -305,29 +314,29 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
             for (int mi = 0; mi < 2; ++mi) {
                 const float4 v = *reinterpret_cast<const float4*>(cb_n + split_image_elem(q, mi));
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < NI; ++ni) {
                     acc[3][split_index(mi, ni, 0)] = v.x; acc[3][split_index(mi, ni, 1)] = v.y;
                     acc[3][split_index(mi, ni, 2)] = v.z; acc[3][split_index(mi, ni, 3)] = v.w;
                 }
             }
         }
         if (t > 0) {                                             // b holds the split of h_{t-1}
-            if (LARGE) lacc = split_tile_mfma<TERMS>(lacc, s_head + (t - 1) * (kSplitTile / 4), b, lane);
+            if (LARGE) lacc = split_tile_mfma<TERMS, NI>(lacc, s_head + (t - 1) * (kSplitTile / 4), b, lane);
             if (LSTM) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = split_tile_mfma<TERMS>(acc[g], s_gate + g * (kSplitTile / 4), b, lane);
+                for (int g = 0; g < 4; ++g) acc[g] = split_tile_mfma<TERMS, NI>(acc[g], s_gate + g * (kSplitTile / 4), b, lane);
             } else {
-                acc[0] = split_tile_mfma<TERMS>(acc[0], s_gate + 0 * (kSplitTile / 4), b, lane);
-                acc[1] = split_tile_mfma<TERMS>(acc[1], s_gate + 1 * (kSplitTile / 4), b, lane);
-                acc[3] = split_tile_mfma<TERMS>(acc[3], s_gate + 2 * (kSplitTile / 4), b, lane);
+                acc[0] = split_tile_mfma<TERMS, NI>(acc[0], s_gate + 0 * (kSplitTile / 4), b, lane);
+                acc[1] = split_tile_mfma<TERMS, NI>(acc[1], s_gate + 1 * (kSplitTile / 4), b, lane);
+                acc[3] = split_tile_mfma<TERMS, NI>(acc[3], s_gate + 2 * (kSplitTile / 4), b, lane);
             }
         }
-        gate_update<LSTM>(acc, h, c);
-        split_state(b, h);                                       // for this step's head and the next step's gates
-        if (!LARGE) split_head_step(lacc, hw, h);
+        gate_update<LSTM, NI>(acc, h, c);
+        split_state<NI>(b, h);                                       // for this step's head and the next step's gates
+        if (!LARGE) split_head_step<NI>(lacc, hw, h);
     }
-    if (LARGE) lacc = split_tile_mfma<TERMS>(lacc, s_head + (kT - 1) * (kSplitTile / 4), b, lane);
-    split_head_epilogue<LARGE>(lacc, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold);
+    if (LARGE) lacc = split_tile_mfma<TERMS, NI>(lacc, s_head + (kT - 1) * (kSplitTile / 4), b, lane);
+    split_head_epilogue<LARGE, NI>(lacc, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold);
 }
 
 // ---------------------------------------------------------------------------------------------

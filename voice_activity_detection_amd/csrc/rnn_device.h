@@ -139,9 +139,10 @@ struct SplitB {
     u32x4 hi[2], mid[2], lo[2];
 };
 
+template <int NI = 2>
 __device__ __forceinline__ void split_state(SplitB& b, const f32x16& h) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             const int j = 2 * jp;                                       // j and j + 1 share j >> 2
@@ -159,20 +160,20 @@ __device__ __forceinline__ void split_state(SplitB& b, const f32x16& h) {
 
 // acc += A . B for one split 32 x 32 tile; `a` points at the tile's [2 mi][3 terms][64 lanes] 16-byte entries
 // (LDS or global memory)
-template <int TERMS>
+template <int TERMS, int NI = 2>
 __device__ __forceinline__ f32x16 split_tile_mfma(f32x16 acc, const u32x4* a, const SplitB& b, int lane) {
     static_assert(TERMS == 6 || TERMS == 9, "6 or 9 partial products");
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const u32x4 ah = a[(mi * 3 + 0) * 64 + lane], am = a[(mi * 3 + 1) * 64 + lane], al = a[(mi * 3 + 2) * 64 + lane];
-        f32x4s c[2];
+        f32x4s c[NI];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int i = 0; i < 4; ++i) c[ni][i] = acc[split_index(mi, ni, i)];
         auto term = [&](const u32x4& at, const u32x4 (&bt)[2]) {
-            c[0] = MFMA_BF16(at, bt[0], c[0]);
-            c[1] = MFMA_BF16(at, bt[1], c[1]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) c[ni] = MFMA_BF16(at, bt[ni], c[ni]);
         };
         if (TERMS == 9) {                                   // smallest terms first
             term(al, b.lo);
@@ -186,7 +187,7 @@ __device__ __forceinline__ f32x16 split_tile_mfma(f32x16 acc, const u32x4* a, co
         term(am, b.hi);
         term(ah, b.hi);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[split_index(mi, ni, i)] = c[ni][i];
     }
@@ -222,10 +223,12 @@ __device__ __forceinline__ void recurrent_mfma(f32x16 (&acc)[4], const f32x16& h
 }
 
 // Gate non-linearities, elementwise in (unit, window).
-template <bool LSTM>
+// (NI = 1: the split layout with one window half per lane uses elements (2 mi) * 4 + i only)
+template <bool LSTM, int NI = 2>
 __device__ __forceinline__ void gate_update(const f32x16 (&acc)[4], f32x16& h, f32x16& c) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+        if (NI == 1 && ((i >> 2) & 1)) continue;
         if (LSTM) {
             const float ig = sigmoid_pre(acc[0][i]);
             const float fg = sigmoid_pre(acc[1][i]);
@@ -348,13 +351,14 @@ __device__ __forceinline__ void split_head_load(SplitHeadWeights& hw, const floa
 }
 
 // lacc[2 ni + o] += sum over the lane's rows of W[o][row] h[row] for window half ni
+template <int NI = 2>
 __device__ __forceinline__ void split_head_step(f32x16& lacc, const SplitHeadWeights& hw, const f32x16& h) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
                 lacc[2 * ni] = fmaf(hw.w[4 * mi + i].x, h[split_index(mi, ni, i)], lacc[2 * ni]);
                 lacc[2 * ni + 1] = fmaf(hw.w[4 * mi + i].y, h[split_index(mi, ni, i)], lacc[2 * ni + 1]);
             }
