@@ -324,7 +324,11 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
             if (LARGE) lacc = split_tile_mfma<TERMS, NI>(lacc, s_head + (t - 1) * (kSplitTile / 4), b, lane);
             if (LSTM) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = split_tile_mfma<TERMS, NI>(acc[g], s_gate + g * (kSplitTile / 4), b, lane);
+                for (int g = 0; g < 4; ++g) {
+                    // five tiles' operand reads hoisted together do not fit the 168 registers of a 12-wave block
+                    if (LARGE) __builtin_amdgcn_sched_barrier(0);
+                    acc[g] = split_tile_mfma<TERMS, NI>(acc[g], s_gate + g * (kSplitTile / 4), b, lane);
+                }
             } else {
                 acc[0] = split_tile_mfma<TERMS, NI>(acc[0], s_gate + 0 * (kSplitTile / 4), b, lane);
                 acc[1] = split_tile_mfma<TERMS, NI>(acc[1], s_gate + 1 * (kSplitTile / 4), b, lane);
