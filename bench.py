@@ -459,6 +459,8 @@ def main():
             torch.cuda.empty_cache()
 
             def all_agree(ok):
+                if not dist:                                     # single-process rehearsal (BENCH_BIG_WORLD=1)
+                    return bool(ok)
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=red_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 return bool(flag.item())
