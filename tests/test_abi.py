@@ -126,3 +126,82 @@ def test_argument_checks_reject_before_any_device_work(L):
         assert needle in L.vad_last_error(), (name, L.vad_last_error())
     assert L.vad_net_blob_floats(1, 1, 33) == 0 and L.vad_net_blob_floats(0, 1, 97) == 0
     assert L.vad_net_blob_floats(0, 1, 30) > 0 and L.vad_densenet_blob_floats(1) > L.vad_densenet_blob_floats(0)
+
+
+def _unit_of_tile_row(r, nu):
+    """Placement of nu < = 32 units on the 32 rows of a tile (rnn_device.h: unit_of_tile_row)."""
+    ks = (nu + 1) // 2
+    kstep = lambda q: (q & 3) + 4 * (q >> 3)
+    if kstep(r) >= ks:
+        return -1
+    rank = sum(1 for q in range(r) if kstep(q) < ks)
+    return rank if rank < nu else -1
+
+
+def _bf16x3(entry_hi, entry_mid, entry_lo):
+    """(64, 8) uint16 images of the three terms -> float64 sum of the three bfloat16 values."""
+    f = lambda e: (e.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    return f(entry_hi) + f(entry_mid) + f(entry_lo)
+
+
+@pytest.mark.parametrize('hidden,lstm', [(30, 0), (30, 1), (17, 0), (90, 0), (40, 0)])
+def test_split_operand_layout(L, hidden, lstm):
+    """Host-only: the bf16 (hi, mid, lo) A operands of v_mfma_f32_16x16x32_bf16 that the packer writes sum back
+    exactly to the scaled float32 weights, at the rows and k-slots the split kernels read them from: lane 16 q + m
+    of entry (tile mt, row half mi, k-block kb) holds tile row 16 mi + m and k-slots 8 q + j = tile rows
+    16 (j >> 2) + 4 q + (j & 3) of tile kb."""
+    H = hidden
+    UT = (H + 31) // 32
+    G = 4 if lstm else 3
+    rng = np.random.default_rng(H)
+    f32 = lambda *s: rng.standard_normal(s).astype(np.float32)
+    LOG2E = 1.4426950408889634
+    scale = [-LOG2E, -LOG2E, 2 * LOG2E, -LOG2E] if lstm else [-LOG2E, -LOG2E, 2 * LOG2E]
+    w_ih, w_hh, b_ih, b_hh = f32(G * H, 24), f32(G * H, H), f32(G * H), f32(G * H)
+    lin1_w, lin1_b, lin2_w, lin2_b, lin_w, lin_b = f32(26, 30 * H), f32(26), f32(2, 26), f32(2), f32(2, 30 * H), f32(2)
+    n = L.vad_net_blob_floats(lstm, 1, H)
+    blob = np.zeros(n, np.float32)
+    hp = _lib.host_ptr
+    assert L.vad_pack_net_weights(lstm, 1, H, hp(w_ih), hp(w_hh), hp(b_ih), hp(b_hh), hp(lin1_w), hp(lin1_b),
+                                  hp(lin2_w), hp(lin2_b), hp(lin_w), hp(lin_b), hp(blob), n) == 0
+    # offsets as in net_layout (rnn_device.h)
+    a_hh = G * UT * 12 * 64
+    cb = a_hh + G * UT * UT * 16 * 64
+    head = cb + 4 * UT * 2 * 16
+    tail = head + 30 * UT * 16 * 64
+    s_hh = tail + (2 * 16 + 2 * 2 * 16 + 4)
+    gate_entries = G * 2 * 3 if UT == 1 else 3 * UT * 2 * UT * 3
+    s_head = s_hh + gate_entries * 256
+    words = blob.view(np.uint16)
+    entry = lambda base_floats, index: words[2 * (base_floats + index * 256): 2 * (base_floats + (index + 1) * 256)].reshape(64, 8)
+    unit = lambda tile, r: (lambda u: -1 if u < 0 else 32 * tile + u)(_unit_of_tile_row(r, min(32, max(0, H - 32 * tile))))
+
+    def check(e_hi, e_mid, e_lo, value_at):
+        got = _bf16x3(e_hi, e_mid, e_lo)
+        for lane in range(64):
+            for j in range(8):
+                want = value_at(lane & 15, 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3))
+                assert got[lane, j] == float(want), (lane, j)
+
+    for g in range(G):
+        for mt in range(UT):
+            for mi in range(2):
+                for kb in range(UT):
+                    def gate_value(m16, p, g=g, mt=mt, mi=mi, kb=kb):
+                        m, u = unit(mt, 16 * mi + m16), unit(kb, p)
+                        return np.float32(0.0) if m < 0 or u < 0 else np.float32(scale[g] * float(w_hh[g * H + m, u]))
+                    if UT == 1:
+                        base = (g * 2 + mi) * 3
+                        check(entry(s_hh, base), entry(s_hh, base + 1), entry(s_hh, base + 2), gate_value)
+                    else:
+                        base = ((g * UT + mt) * 2 + mi) * UT + kb
+                        hm = 3 * UT * 2 * UT * 2
+                        check(entry(s_hh, 2 * base), entry(s_hh, 2 * base + 1), entry(s_hh, hm + base), gate_value)
+    for t in (0, 13, 29):
+        for mi in range(2):
+            for kb in range(UT):
+                def head_value(m16, p, t=t, mi=mi, kb=kb):
+                    o, u = 16 * mi + m16, unit(kb, p)
+                    return np.float32(0.0) if o >= 26 or u < 0 else lin1_w[o, t * H + u]
+                base = (t * 2 + mi) * 3 if UT == 1 else ((t * 2 + mi) * UT + kb) * 3
+                check(entry(s_head, base), entry(s_head, base + 1), entry(s_head, base + 2), head_value)
