@@ -257,6 +257,28 @@ __device__ __forceinline__ void stem_pair(const float* xe_row, const float* __re
         for (int i = 0; i < 16; ++i) out(mt, i, lrelu(fmaxf(acc_e[mt][i], acc_o[mt][i])));
 }
 
+// Stem convolution + BN at ONE position per column: acc[mt] = S[row] for the lane's channels, the value stem_pair
+// computes as its "even" half (the same fmaf chain).
+template <bool LARGE>
+__device__ __forceinline__ void stem_single(const float* x_row, const float* __restrict__ blob, const DnLayout& LY, int lane,
+                                            int half, f32x16 (&acc)[Dims<LARGE>::mt0]) {
+    using D = Dims<LARGE>;
+#pragma unroll
+    for (int mt = 0; mt < D::mt0; ++mt) acc[mt] = load_shift(blob + LY.s_in + mt * 32, half);
+#pragma unroll
+    for (int j = 0; j < kTaps; ++j) {
+        const float* re = x_row + 4 * j * kF;                    // tap j reads the row 4 j later (dilation 4)
+        const float4 e0 = *reinterpret_cast<const float4*>(re), e1 = *reinterpret_cast<const float4*>(re + 4),
+                     e2 = *reinterpret_cast<const float4*>(re + 8);
+        const float xe[12] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w};
+#pragma unroll
+        for (int s = 0; s < 12; ++s)
+#pragma unroll
+            for (int mt = 0; mt < D::mt0; ++mt)
+                acc[mt] = MFMA(blob[LY.a_in + ((mt * kTaps + j) * 12 + s) * 64 + lane], xe[s], acc[mt]);
+    }
+}
+
 // Everything after the stem for a wave's 32 windows: dense block 1 over `v1`, transition into the plain
 // private array act2[c][2][32] (which may alias v1's growth region), dense block 2, cnn_out, Linear, softmax.
 // `dense_w[b]` points at the growth-layer weights of dense block b (the blob's, or a copy in LDS).
@@ -401,13 +423,13 @@ __global__ __launch_bounds__(64) void densenet_kernel(const float* __restrict__ 
 // M[w + 2 lp], M[r] = LeakyReLU(max(S[r], S[r + 1])) with S[r] the stem convolution at absolute row r:
 // it belongs to the row, not to the window, and ten overlapping windows would each recompute it.  A block
 // of NW = 8 waves computes M once for its NW * 32 rows (one 32-row tile per wave) into a shared LDS image and
-// then scores its NW * 32 - 8 windows from it; only the growth channels are private to a wave.
+// then scores its NW * 32 - 9 windows from it; only the growth channels are private to a wave.
 template <bool LARGE>
 struct DnStreamCfg {
     using D = Dims<LARGE>;
     static constexpr int waves = LARGE ? 8 : 12;
     static constexpr int rows = waves * 32;                      // M rows per block
-    static constexpr int windows = rows - 8;                     // window w reads M[w .. w + 8]
+    static constexpr int windows = rows - 9;                     // window w reads M[w .. w + 8], M[r] needs S[r + 1]
     // 6 KB (small) / 12.8 KB (large) of private LDS per wave: 12 waves = three per SIMD (small), 8 waves = two per
     // SIMD (large) share a CU
     static constexpr int reg1 = D::reg1, reg2 = D::reg2, priv = D::priv;
@@ -416,6 +438,7 @@ struct DnStreamCfg {
     static constexpr bool dense_in_lds = !LARGE;
     // (+ 16 floats: a layer whose register-resident inputs end on an even channel reads one row past its weights)
     static constexpr int dense_floats = dense_in_lds ? 2 * dense_layer_offset(D::c0, D::g, D::nl) + 16 : 0;
+    static_assert(waves * priv >= D::c0 * rows, "the S image of phase 1 fits the private regions it aliases");
     static constexpr int lds_floats = D::c0 * rows + waves * priv + dense_floats;
 };
 
@@ -442,19 +465,41 @@ __global__ __launch_bounds__(DnStreamCfg<LARGE>::waves * 64) void densenet_strea
     const long w0 = (long)blockIdx.x * C::windows;
     const long last_row = n_windows + VAD_FRAMES - 2;            // the matrix has n_windows + 29 rows
 
-    // ---- phase 1: M for rows w0 + 32 wave + col.  S[r + 1] with tap 5 reads row r + 21; rows past the
-    // matrix (only reached by M entries that no valid window uses) are clamped to its last row. ----
+    // ---- phase 1: S[r], the stem convolution at row r = w0 + 32 wave + col, once per row (a window-by-window
+    // evaluation computes every S twice, as the second half of one pooled pair and the first of the next); tap 5
+    // reads row r + 20, rows past the matrix (only reached by entries that no valid window uses) are clamped to its
+    // last rows.  The S image aliases the waves' private regions, unused until phase 2. ----
+    float* S = lds + D::c0 * C::rows;                            // [c0][rows]
+    f32x16 sv[D::mt0];
     {
         const long r = w0 + wave * 32 + col;
-        const long rc = r + 21 <= last_row ? r : (last_row - 21 > 0 ? last_row - 21 : 0);
-        stem_pair<LARGE>(feat + rc * kF + 12 * half, blob, LY, lane, half, [&](int mt, int i, float y) {
-            const int c = 32 * mt + mfma32_row(i, half);
-            if (c < D::c0) M[c * C::rows + wave * 32 + col] = y;
-        });
+        const long rc = r + 20 <= last_row ? r : (last_row - 20 > 0 ? last_row - 20 : 0);
+        stem_single<LARGE>(feat + rc * kF + 12 * half, blob, LY, lane, half, sv);
+#pragma unroll
+        for (int mt = 0; mt < D::mt0; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 32 * mt + mfma32_row(i, half);
+                if (c < D::c0) S[c * C::rows + wave * 32 + col] = sv[mt][i];
+            }
+    }
+    __syncthreads();
+    // M[r] = LeakyReLU(max(S[r], S[r + 1])): the lane's own S[r] and its neighbour's S[r + 1] (the block's last row
+    // has no neighbour: its M entry is not used by the block's windows)
+    {
+        const int rl = wave * 32 + col;
+        const int rn = rl + 1 < C::rows ? rl + 1 : rl;
+#pragma unroll
+        for (int mt = 0; mt < D::mt0; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = 32 * mt + mfma32_row(i, half);
+                if (c < D::c0) M[c * C::rows + rl] = lrelu(fmaxf(sv[mt][i], S[c * C::rows + rn]));
+            }
     }
     __syncthreads();
 
-    // ---- phase 2: the wave's 32 windows (the last wave of a block owns 24) ----
+    // ---- phase 2: the wave's 32 windows (the last wave of a block owns 23) ----
     const int wl = wave * 32 + col;                              // window index inside the block
     const bool owned = wl < C::windows;
     const long w = owned ? w0 + wl : n_windows;                  // not owned: masked at the store
