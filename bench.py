@@ -90,7 +90,7 @@ def split_mode_applies(model):
 def model_peak(model, mode):
     """The float32 flop rate the hardware could sustain on a model's algorithmic work.  float32 MFMA and float32
     vector work share one pipe (157.3 TF).  In the bf16 split modes the recurrent and 26-row head products run as
-    9 (or 6) bf16 partial products each on the bf16 matrix pipe, beside the rest of the work (projection, gate
+    9, 8 or 6 bf16 partial products each on the bf16 matrix pipe, beside the rest of the work (projection, gate
     math, 2-row head) on the float32 pipe: the slower of the two pipes bounds it."""
     if mode == 'f32' or not split_mode_applies(model):
         return PEAK_FP32_TFLOPS
@@ -276,10 +276,10 @@ def main():
     ap.add_argument('--slice', type=int, default=166, help='frames per MFCC slice (reference test path: 166)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-configs', action='store_true', help='time the headline workload only')
-    ap.add_argument('--matrix-mode', default='bf16x9', choices=['f32', 'bf16x6', 'bf16x9'],
+    ap.add_argument('--matrix-mode', default='bf16x8', choices=['f32', 'bf16x6', 'bf16x8', 'bf16x9'],
                     help="how the stride-1 GRU/LSTM kernels form float32 products (default: the library's default, "
-                         'bf16x9 = float32 operands split exactly into three bf16, all nine exact partial products '
-                         'accumulated in float32 on the bf16 matrix pipe)')
+                         'bf16x8 = float32 operands split exactly into three bf16, the partial products accumulated '
+                         'in float32 on the bf16 matrix pipe, all but lo * lo, which is under 2^-30 of a product)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -389,9 +389,9 @@ def main():
             'note': 'achieved = algorithmic float32 flops / time, with the per-row work (input projection / DenseNet '
                     'stem) counted once per feature row as stride-1 windows need it; flop_per_window_pytorch counts '
                     'it per (30,24) window as a batch framework does.  peak: 157.3 TF (fp32 MFMA = fp32 vector rate) '
-                    'for float32-MFMA kernels; in the bf16x9 / bf16x6 matrix modes every float32 product of the '
-                    'recurrence and the 26-row head costs 9 / 6 bf16 products, so the peak for that work is '
-                    '2500 TF / 9 (or 6), taken beside the float32 pipe for the rest'}
+                    'for float32-MFMA kernels; in the bf16x9 / bf16x8 / bf16x6 matrix modes every float32 product of the '
+                    'recurrence and the 26-row head costs 9 / 8 / 6 bf16 products, so the peak for that work is '
+                    '2500 TF / 9 (8, 6), taken beside the float32 pipe for the rest'}
         fe_gbs = FRONTEND_BYTES_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e9
         fe_tf = FRONTEND_FLOP_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e12
         fe_pmc = pmc_per_unit(prof, 'mfcc_kernel')
@@ -442,7 +442,7 @@ def main():
                'roofline': head['roofline'], 'roofline_choice': head['roofline_choice'], 'kernels': head['kernels'],
                'matrix_mode': args.matrix_mode}
 
-    if not args.no_configs and args.model == 'gru_large' and args.matrix_mode == 'bf16x9':
+    if not args.no_configs and args.model == 'gru_large' and args.matrix_mode == 'bf16x8':
         # The other configurations of the measurement plan, 3 steps each on the buffers of the headline run:
         # LSTM-small, DenseNet small and large, and the enlarged GRU (hidden 90).  With 8 ranks the enlarged
         # GRU runs at its named size, 10 000 h over the node = 1 250 h (144 GB of int16) per GPU.
@@ -480,13 +480,13 @@ def main():
         if rank == 0:
             out['configs'] = extra
 
-    if rank == 0 and world == 1 and args.matrix_mode == 'bf16x9' and \
+    if rank == 0 and world == 1 and args.matrix_mode == 'bf16x8' and \
             args.model in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
         # Not part of `value`: the same step in the other matrix modes of the stride-1 GRU / LSTM kernels
-        # (vad_set_matrix_mode) -- the float32 MFMA (a k-ordered FMA chain) and bf16x6 -- and how far the
+        # (vad_set_matrix_mode) -- the float32 MFMA (a k-ordered FMA chain), bf16x9 and bf16x6 -- and how far the
         # posteriors of each mode are from the float32-MFMA ones over every window of the workload.
         alt, ps = {}, {}
-        for mm in ('f32', 'bf16x9', 'bf16x6'):
+        for mm in ('f32', 'bf16x9', 'bf16x8', 'bf16x6'):
             pkg.set_matrix_mode(mm)
             current_mode[0] = mm
             rec, buffers = run_workload(args.model, args.hours, 3, 1, buffers)

@@ -202,7 +202,7 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
  * How the stride-1 (window_stride == 24) GRU / LSTM kernels with hidden <= 32, and the wider GRUs' stride-1
  * workspace path (vad_gru_forward_ws_f32), form the float32 products of the recurrence and of the 26-row head.
  * Process-wide; no counterpart in the reference.
- *   VAD_MATRIX_BF16X9  (default) every float32 operand is split exactly into three bfloat16 (x = hi + mid + lo)
+ *   VAD_MATRIX_BF16X9  every float32 operand is split exactly into three bfloat16 (x = hi + mid + lo)
  *                      and all nine partial products, each exact in float32, are accumulated in float32 on the
  *                      bf16 matrix pipe (v_mfma_f32_16x16x32_bf16): no operand or product is rounded, only the
  *                      accumulation is, as in a float32 FMA chain but in a different order and with the matrix
@@ -211,6 +211,10 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
  *                      to C and rounded to nearest (measured by tools/probes/mfma_bf16_accum_k32.hip), which
  *                      bounds a K = 32 dot product's error
  *                      by about 68 * 2^-24 * the largest magnitude in the chain (float32 FMA chain: 30 * 2^-24).
+ *   VAD_MATRIX_BF16X8  (default) as BF16X9 without the lo * lo partial product: the operands are split by
+ *                      truncation, so |lo| < 2^-15 |x| and the dropped term is below 2^-30 of the product it
+ *                      belongs to, 1/64 of the rounding unit of a single float32 operation; it adds
+ *                      2^-30 * sum |a b| (under 2^-6 * 2^-24 of the chain's magnitude per term) to the bound above.
  *   VAD_MATRIX_F32     v_mfma_f32_32x32x2_f32: a float32 FMA chain in k order, bit-identical to what every other
  *                      path of this library computes (dense batches, other strides, sampled windows).
  *   VAD_MATRIX_BF16X6  as BF16X9 without the three smallest partial products (<= 2^-23 of a product).
@@ -219,6 +223,7 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
 #define VAD_MATRIX_F32 0
 #define VAD_MATRIX_BF16X6 1
 #define VAD_MATRIX_BF16X9 2
+#define VAD_MATRIX_BF16X8 3
 int vad_set_matrix_mode(int mode);
 int vad_get_matrix_mode(void);
 

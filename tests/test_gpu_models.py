@@ -80,14 +80,14 @@ def test_ragged_batches_match_oracle(vad, kind, batch):
 @pytest.mark.parametrize('kind', list(NET_KINDS))
 def test_fixture_through_the_stride1_kernels(vad, golden_dir, kind):
     """The reference-generated fixture through the stride-1 GRU / LSTM kernels in every matrix mode (the default,
-    bf16x9, first): the 64 fixture windows are laid end to end as a (1920,24) feature matrix, whose stride-1
+    bf16x8, first): the 64 fixture windows are laid end to end as a (1920,24) feature matrix, whose stride-1
     windows 0, 30, 60, ... are exactly the fixture windows."""
     sd, x, y = _fixture(golden_dir, kind)
     net = _make(vad, kind)
     net.load_state_dict(sd)
     feat = torch.from_numpy(x.reshape(-1, 24)).cuda()
-    assert vad.lib().vad_get_matrix_mode() == 2                       # VAD_MATRIX_BF16X9 is the default
-    for mode in ('bf16x9', 'bf16x6', 'f32'):
+    assert vad.lib().vad_get_matrix_mode() == 3                       # VAD_MATRIX_BF16X8 is the default
+    for mode in ('bf16x8', 'bf16x9', 'bf16x6', 'f32'):
         prev = vad.set_matrix_mode(mode)
         try:
             p, _ = net.score(feat, window_stride=24)
@@ -119,10 +119,10 @@ def test_sliding_windows_equal_explicit_windows(vad, kind, f32_matrix_mode):
     # strided windows (STEP_SIZE = 6, core/train.py:54)
     p6, _ = net.score(fdev, window_stride=24 * 6)
     assert torch.equal(p6, p_slide[::6])
-    # the default matrix mode of the stride-1 kernels (bf16x9) holds the same bar against the oracle
-    vad.set_matrix_mode('bf16x9')
-    p_x9, _ = net.score(fdev, window_stride=24)
-    assert np.abs(p_x9.cpu().numpy() - y).max() <= ATOL
+    # the default matrix mode of the stride-1 kernels (bf16x8) holds the same bar against the oracle
+    vad.set_matrix_mode('bf16x8')
+    p_x8, _ = net.score(fdev, window_stride=24)
+    assert np.abs(p_x8.cpu().numpy() - y).max() <= ATOL
 
 
 @pytest.mark.parametrize('kind', ['gru_large', 'lstm_small'])
@@ -319,7 +319,7 @@ def test_generator_feeds_models_without_batches(vad):
     assert len(scores['rows'][1]) > 0
 
 
-@pytest.mark.parametrize('mode', ['bf16x9', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['bf16x8', 'bf16x9', 'bf16x6'])
 @pytest.mark.parametrize('kind', ['gru_large', 'gru_small', 'lstm_large', 'lstm_small'])
 def test_split_bf16_matrix_modes(vad, kind, mode):
     """The stride-1 kernels with the products on the bf16 matrix pipe (float32 operands split exactly into
@@ -363,7 +363,7 @@ def test_split_kernels_at_ragged_window_counts(vad, kind):
     windows = torch.stack([torch.from_numpy(feat_np[i:i + 30]) for i in range(571)])
     with torch.no_grad():
         y = ref(windows).numpy()
-    prev = vad.set_matrix_mode('bf16x9')
+    prev = vad.set_matrix_mode('bf16x8')
     try:
         for n in (1, 15, 16, 17, 31, 32, 33, 191, 192, 193, 255, 256, 257, 571):
             p = torch.full((n + 3, 2), -7.0, device='cuda')
@@ -376,7 +376,7 @@ def test_split_kernels_at_ragged_window_counts(vad, kind):
         vad.set_matrix_mode(prev)
 
 
-@pytest.mark.parametrize('mode', ['bf16x9', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['bf16x8', 'bf16x9', 'bf16x6'])
 @pytest.mark.parametrize('hidden,large', [(90, True), (90, False), (64, True), (40, False), (33, True)])
 def test_wide_gru_split_kernel(vad, hidden, large, mode):
     """Stride-1 windows of the wide GRU with the products on the bf16 matrix pipe: within the bar of the float32

@@ -48,7 +48,7 @@ for kind in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
     with torch.no_grad():
         y64 = r.double()(x64).numpy()
     row = ['torch-cpu-f32 %.2e' % np.abs(y32 - y64).max()]
-    for mode in ('f32', 'bf16x9', 'bf16x6'):
+    for mode in ('f32', 'bf16x9', 'bf16x8', 'bf16x6'):
         pkg.set_matrix_mode(mode)
         p, _ = net.score(fdev, window_stride=24)
         row.append('%s max %.2e mean %.2e' % (mode, np.abs(p.cpu().numpy() - y64).max(), np.abs(p.cpu().numpy() - y64).mean()))

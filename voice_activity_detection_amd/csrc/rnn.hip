@@ -52,7 +52,7 @@ namespace vad {
 using namespace rnn;
 
 // How the stride-1 GRU / LSTM kernels form their float32 matrix products (vad_set_matrix_mode).
-std::atomic<int> g_matrix_mode{VAD_MATRIX_BF16X9};
+std::atomic<int> g_matrix_mode{VAD_MATRIX_BF16X8};
 
 namespace {
 
@@ -668,8 +668,8 @@ __device__ __forceinline__ void wide_split_terms(f32x4s (&c)[NI], const u32x4& a
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) c[ni] = MFMA_BF16(at, bt[ni], c[ni]);
     };
-    if (TERMS == 9) {
-        term(al, b.lo[kb]);
+    if (TERMS == 9) term(al, b.lo[kb]);
+    if (TERMS >= 8) {
         term(am, b.lo[kb]);
         term(al, b.mid[kb]);
     }
@@ -899,6 +899,8 @@ template <bool LARGE, int UT>
 int allow_wide_split() {
     int rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, 9, kWideSplitNi>, wide_split_lds_floats(UT));
     if (rc != VAD_OK) return rc;
+    rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, 8, kWideSplitNi>, wide_split_lds_floats(UT));
+    if (rc != VAD_OK) return rc;
     return allow_lds(&gru_wide_split_kernel<LARGE, UT, 6, kWideSplitNi>, wide_split_lds_floats(UT));
 }
 
@@ -926,6 +928,10 @@ int ensure_rnn_attrs() {
     if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 6>, SplitCfg<false>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 6>, SplitCfg<true>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_split_kernel<true, true, 6>, SplitCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<false, false, 8>, SplitCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 8>, SplitCfg<false>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 8>, SplitCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_lds(&rnn_stream_split_kernel<true, true, 8>, SplitCfg<true>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_split_kernel<false, false, 9>, SplitCfg<false>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 9>, SplitCfg<false>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 9>, SplitCfg<true>::lds_floats))) return rc;
@@ -979,6 +985,10 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
                 hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 9, kWideSplitNi>), dim3((unsigned)sblocks),
                                    dim3(64 * SC::waves), split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0,
                                    dec ? dec + w0 : nullptr, mode, threshold);
+            else if (matrix_mode == VAD_MATRIX_BF16X8)
+                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 8, kWideSplitNi>), dim3((unsigned)sblocks),
+                                   dim3(64 * SC::waves), split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0,
+                                   dec ? dec + w0 : nullptr, mode, threshold);
             else if (matrix_mode == VAD_MATRIX_BF16X6)
                 hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 6, kWideSplitNi>), dim3((unsigned)sblocks),
                                    dim3(64 * SC::waves), split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0,
@@ -1024,6 +1034,9 @@ int launch_ks(const float* x, long n_windows, WindowMap wm, const float* blob, f
         VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
         if (matrix_mode == VAD_MATRIX_BF16X9)
             hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, 9>), dim3((unsigned)blocks), dim3(C::waves * 64),
+                               lds_bytes, st, x, n_windows, blob, p, dec, mode, threshold);
+        else if (matrix_mode == VAD_MATRIX_BF16X8)
+            hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, 8>), dim3((unsigned)blocks), dim3(C::waves * 64),
                                lds_bytes, st, x, n_windows, blob, p, dec, mode, threshold);
         else
             hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, 6>), dim3((unsigned)blocks), dim3(C::waves * 64),
@@ -1097,7 +1110,8 @@ int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, cons
 }  // namespace vad
 
 extern "C" int vad_set_matrix_mode(int mode) {
-    VAD_REQUIRE(mode == VAD_MATRIX_F32 || mode == VAD_MATRIX_BF16X6 || mode == VAD_MATRIX_BF16X9,
+    VAD_REQUIRE(mode == VAD_MATRIX_F32 || mode == VAD_MATRIX_BF16X6 || mode == VAD_MATRIX_BF16X9 ||
+                    mode == VAD_MATRIX_BF16X8,
                 "unknown matrix mode %d", mode);
     vad::g_matrix_mode.store(mode, std::memory_order_relaxed);
     return VAD_OK;

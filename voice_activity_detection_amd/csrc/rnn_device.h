@@ -111,7 +111,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // A float32 is the exact sum of three bfloat16 (8 + 8 + 8 significant bits, by truncation: hi = the upper
 // 16 bits, mid = the upper 16 bits of x - hi, lo = x - hi - mid).  x * y is then the exact sum of the nine
 // bf16 x bf16 partial products, each of which the bf16 MFMA forms exactly and adds in float32.
-// With all 9 terms the only rounding left is the float32 accumulation, as in a float32 FMA chain; with 6
+// With all 9 terms the only rounding left is the float32 accumulation, as in a float32 FMA chain; with 8
+// terms lo*lo is dropped (< 2^-30 of the product, 1/64 of the rounding of one float32 operation); with 6
 // terms the three smallest (mid*lo, lo*mid, lo*lo, <= 2^-23 of the product) are dropped.  The bf16 matrix
 // pipe does K = 32 of a 32 x 32 tile in 64 cycles against 16 x 64 cycles on the float32 MFMA, and unlike the
 // float32 MFMA it runs beside vector instructions.
@@ -162,7 +163,7 @@ __device__ __forceinline__ void split_state(SplitB& b, const f32x16& h) {
 // (LDS or global memory)
 template <int TERMS, int NI = 2>
 __device__ __forceinline__ f32x16 split_tile_mfma(f32x16 acc, const u32x4* a, const SplitB& b, int lane) {
-    static_assert(TERMS == 6 || TERMS == 9, "6 or 9 partial products");
+    static_assert(TERMS == 6 || TERMS == 8 || TERMS == 9, "6, 8 or 9 partial products");
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const u32x4 ah = a[(mi * 3 + 0) * 64 + lane], am = a[(mi * 3 + 1) * 64 + lane], al = a[(mi * 3 + 2) * 64 + lane];
@@ -175,8 +176,8 @@ __device__ __forceinline__ f32x16 split_tile_mfma(f32x16 acc, const u32x4* a, co
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) c[ni] = MFMA_BF16(at, bt[ni], c[ni]);
         };
-        if (TERMS == 9) {                                   // smallest terms first
-            term(al, b.lo);
+        if (TERMS == 9) term(al, b.lo);                     // smallest terms first
+        if (TERMS >= 8) {
             term(am, b.lo);
             term(al, b.mid);
         }

@@ -19,16 +19,17 @@ from .common import BATCH_SIZE, FEATURES, FRAMES
 
 DECIDE_ARGMAX = 0
 DECIDE_THRESHOLD = 1
-MATRIX_MODES = {'f32': 0, 'bf16x6': 1, 'bf16x9': 2}
+MATRIX_MODES = {'f32': 0, 'bf16x6': 1, 'bf16x9': 2, 'bf16x8': 3}
 
 
 def set_matrix_mode(mode):
     """Process-wide: how the stride-1 GRU / LSTM kernels (and the wide GRU's stride-1 workspace path) form their
     float32 matrix products.
-    'bf16x9' (default) splits every float32 operand exactly into three bfloat16 and accumulates all nine exact
-    partial products in float32 on the bf16 matrix pipe; 'f32' is the float32 MFMA (a k-ordered FMA chain,
-    bit-identical to the dense-batch and sampled-window paths); 'bf16x6' drops the three smallest partial
-    products.  Returns the previous mode's name."""
+    'bf16x9' splits every float32 operand exactly into three bfloat16 and accumulates all nine exact partial
+    products in float32 on the bf16 matrix pipe; 'bf16x8' (default) leaves out the lo * lo product, under 2^-30
+    of the product it belongs to; 'f32' is the float32 MFMA (a k-ordered FMA chain, bit-identical to the
+    dense-batch and sampled-window paths); 'bf16x6' drops the three smallest partial products (up to 2^-23).
+    Returns the previous mode's name."""
     L = _lib.lib()
     if mode not in MATRIX_MODES:
         raise ValueError('matrix mode must be one of %s' % sorted(MATRIX_MODES))
