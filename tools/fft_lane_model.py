@@ -1,8 +1,9 @@
 """Lane-level numpy model of the 1024-point complex FFT + real untangle used by the MFCC kernel.
 
-Mirrors the kernel's data movement (64 lanes x 16 registers, radix 4 x 16 x 16 with two LDS
-exchanges, transposed Z image, paired untangle) so the index arithmetic can be checked against
-numpy.fft on the CPU before it is written in HIP.
+Mirrors the kernel's data movement (64 lanes x 16 registers; radix 16 in registers, one LDS exchange,
+radix 16 in registers, radix 4 across the four lanes of a quad; paired untangle with the partner value
+fetched from another lane) so the index arithmetic can be checked against numpy.fft on the CPU before it
+is written in HIP.
 """
 import numpy as np
 
@@ -28,59 +29,67 @@ def dft16(v):
     return out
 
 
-S1 = 272    # exchange-1 row stride (complex)
-S2 = 272    # exchange-2 plane stride (complex); row stride 17
+S = 68                                  # exchange row stride (complex)
+REV = np.array([0, 2, 1, 3])            # the quad stage leaves output p = REV[a] in lane a
 
 
 def fft1024_lanes(z):
-    """Returns Zt[q2][lane] with lane = 16 k1 + q1 holding Z[k1 + 4 q1 + 64 q2]."""
+    """Returns v[lane][q]: lane = 4 k1 + a holds Z[k1 + 16 q + 256 REV[a]]."""
     L = np.arange(64)
     v = z[L[:, None] + 64 * np.arange(16)[None, :]].copy()          # v[lane][jj], n = lane + 64 jj
-    # pass A: radix 4 over n1 = jj >> 2 for each b = jj & 3; result index 4 k1 + b; twiddle W1024^(n2 k1)
-    for b in range(4):
-        o = dft4(v[:, b], v[:, 4 + b], v[:, 8 + b], v[:, 12 + b])
-        for k1 in range(4):
-            v[:, 4 * k1 + b] = o[k1] * np.exp(-2j * np.pi * ((L + 64 * b) * k1) / 1024)
-    # exchange 1: lds[k1 * S1 + n2]; lane (k1 = lane >> 4, c = lane & 15) reads n2 = c + 16 m
-    lds = np.zeros(4 * S1, complex)
-    for k1 in range(4):
-        for b in range(4):
-            lds[k1 * S1 + L + 64 * b] = v[:, 4 * k1 + b]
-    k1 = L >> 4
-    c = L & 15
-    v = lds[(k1 * S1 + c)[:, None] + 16 * np.arange(16)[None, :]]  # v[lane][m]
-    # pass B: DFT-16 over m -> q1; twiddle W256^(c q1)
-    v = dft16(v) * np.exp(-2j * np.pi * (c[:, None] * np.arange(16)[None, :]) / 256)
-    # exchange 2: lds[k1 * S2 + q1 * 17 + c]; lane (k1, q1 = lane & 15) reads c = 0..15
-    lds = np.zeros(4 * S2 + 16, complex)
-    for q1 in range(16):
-        lds[k1 * S2 + q1 * 17 + c] = v[:, q1]
-    q1 = L & 15
-    v = lds[(k1 * S2 + q1 * 17)[:, None] + np.arange(16)[None, :]]  # v[lane][c]
-    # pass C: DFT-16 over c -> q2 ; k = k1 + 4 q1 + 64 q2
-    v = dft16(v)
-    return v.T.copy()                                               # Zt[q2][lane]
+    # pass A: DFT-16 over jj -> k1; twiddle W1024^(lane k1)
+    v = dft16(v) * np.exp(-2j * np.pi * (L[:, None] * np.arange(16)[None, :]) / 1024)
+    # the exchange: lds[k1 * S + n2]; lane (k1 = lane >> 2, a = lane & 3) reads n2 = a + 4 b
+    lds = np.zeros(16 * S, complex)
+    for k1 in range(16):
+        lds[k1 * S + L] = v[:, k1]
+    k1, a = L >> 2, L & 3
+    v = lds[(k1 * S + a)[:, None] + 4 * np.arange(16)[None, :]]     # v[lane][b]
+    # pass B: DFT-16 over b -> q; twiddle W64^(a q); lanes 1..3 of a quad hold their values negated
+    sgn = np.array([1, -1, -1, -1])[a]
+    v = dft16(v) * np.exp(-2j * np.pi * (a[:, None] * np.arange(16)[None, :]) / 64) * sgn[:, None]
+    # pass C: radix 4 across the quad, r += c * (partner's r), lane 3 turned by i in between
+    c1 = np.array([-1, 1, 1, -1])[a]
+    c2 = np.array([-1, 1, -1, 1])[a]
+    v = v + c1[:, None] * v[L ^ 2]
+    v = np.where((a == 3)[:, None], 1j * v, v)
+    v = v + c2[:, None] * v[L ^ 1]
+    return v
 
 
-def power_from_zt(Zt):
-    """Paired untangle: lane handles k = k1 + 4 q1 + 64 jj (jj < 8) together with 1024 - k."""
-    P = np.zeros(1025)
-    L = np.arange(64)
-    k1, q1 = L >> 4, L & 15
-    lp = np.where(k1 != 0, 16 * (4 - k1) + 15 - q1, np.where(q1 != 0, 16 - q1, 0))
-    d = (L == 0).astype(int)
-    zt = Zt.reshape(-1)
-    for jj in range(8):
-        k = k1 + 4 * q1 + 64 * jj
-        a = zt[jj * 64 + L]
-        b = zt[((15 - jj + d) & 15) * 64 + lp]
-        E = a + np.conj(b)
-        O = a - np.conj(b)
-        wo = np.exp(-2j * np.pi * k / 2048) * O
-        P[k] = ((E.real + wo.imag) ** 2 + (E.imag - wo.real) ** 2) * 0.25
-        P[1024 - k] = ((E.real - wo.imag) ** 2 + (E.imag + wo.real) ** 2) * 0.25
-    P[512] = abs(zt[8 * 64 + 0]) ** 2
-    return P
+def fft_bin(lane, u):
+    """The bin k whose pair (k, 1024 - k) a lane works on in untangle step u (csrc/mfcc_device.h: fft_bin)."""
+    k1, a = lane >> 2, lane & 3
+    if k1 == 0 and u == 0 and a in (1, 3):
+        return 128 + 256 * REV[a]
+    return k1 + 16 * u + 256 * REV[a]
+
+
+def power_from_lanes(v):
+    """Paired untangle; returns the power spectrum and how many times each bin was written."""
+    P = np.full(1025, np.nan)
+    cnt = np.zeros(1025, int)
+    for lane in range(64):
+        k1, a = lane >> 2, lane & 3
+        for u in range(8):
+            k = fft_bin(lane, u)
+            if k1:
+                A, B = v[lane, u], v[4 * (16 - k1) + 3 - a, 15 - u]
+            elif u:
+                A, B = v[lane, u], v[3 - a, 16 - u]
+            else:
+                A = v[lane, 8 if a in (1, 3) else 0]
+                B = [v[0, 0], v[2, 8], v[3, 0], v[0, 8]][a]
+            E = A + np.conj(B)
+            O = A - np.conj(B)
+            wo = np.exp(-2j * np.pi * k / 2048) * O
+            P[k] = ((E.real + wo.imag) ** 2 + (E.imag - wo.real) ** 2) * 0.25
+            P[1024 - k] = ((E.real - wo.imag) ** 2 + (E.imag + wo.real) ** 2) * 0.25
+            cnt[k] += 1
+            cnt[1024 - k] += 1
+    P[512] = abs(v[1, 0]) ** 2
+    cnt[512] += 1
+    return P, cnt
 
 
 if __name__ == '__main__':
@@ -88,12 +97,12 @@ if __name__ == '__main__':
     x = np.zeros(2048)
     x[:1920] = rng.normal(size=1920)
     z = x[0::2] + 1j * x[1::2]
-    Zt = fft1024_lanes(z)
+    v = fft1024_lanes(z)
     Z = np.zeros(1024, complex)
-    for q2 in range(16):
-        for lane in range(64):
-            Z[(lane >> 4) + 4 * (lane & 15) + 64 * q2] = Zt[q2, lane]
+    for lane in range(64):
+        for q in range(16):
+            Z[(lane >> 2) + 16 * q + 256 * REV[lane & 3]] = v[lane, q]
     print('fft err', np.abs(Z - np.fft.fft(z)).max())
-    P = power_from_zt(Zt)
+    P, cnt = power_from_lanes(v)
     ref = np.abs(np.fft.rfft(x)) ** 2
-    print('power err', np.abs(P[1:1024] - ref[1:1024]).max() / ref.max(), 'P[512] err', abs(P[512] - ref[512]))
+    print('power err', np.abs(P - ref).max() / ref.max(), 'writes per bin', np.unique(cnt))

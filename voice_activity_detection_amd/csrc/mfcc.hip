@@ -9,15 +9,14 @@
 // at core/process_data.py:272-276 of the reference (rectangular window,
 // nfft 2048, 26 filters, ortho DCT, lifter 22, c0 dropped).
 //
-// FFT decomposition (N = 1024 = 4 x 16 x 16), all index algebra mirrored by
+// FFT decomposition (N = 1024 = 16 x 16 x 4), all index algebra mirrored by
 // tools/fft_lane_model.py:
-//   pass A  lane L holds z[L + 64 jj]; radix-4 over jj >> 2 in registers; twiddle W1024^(n2 k1)
-//   xchg 1  through LDS: lane (k1, c) gathers the 16 points n2 = c + 16 m of sub-transform k1
-//   pass B  radix-16 over m in registers; twiddle W256^(c q1)
-//   xchg 2  through LDS: lane (k1, q1) gathers the 16 points c
-//   pass C  radix-16 over c in registers
-//   result  lane 16 k1 + q1, register q2 holds Z[k1 + 4 q1 + 64 q2]
-// The real-input untangle works on the pairs (k, 1024 - k), k < 512, that share Z[k] and Z[1024 - k]:
+//   pass A  lane L holds z[L + 64 jj]; radix-16 over jj in registers; twiddle W1024^(L k1)
+//   xchg    through LDS: lane (k1, a) = 4 k1 + a gathers the 16 points n2 = a + 4 b of sub-transform k1
+//   pass B  radix-16 over b in registers; twiddle W64^(a q)
+//   pass C  radix-4 over a across the four lanes of a quad (DPP operands of the butterflies' adds, no LDS)
+//   result  lane 4 k1 + a, register q holds Z[k1 + 16 q + 256 rev(a)], rev = (0, 2, 1, 3)
+// The real-input untangle works on the pairs (k, 1024 - k) that share Z[k] and Z[1024 - k]:
 // the partner value is a register of another lane (ds_bpermute, no LDS image of Z); the power spectrum
 // is left in LDS for the mel stage.
 //
@@ -30,7 +29,7 @@
 // never wait for each other after the block's set-up.
 //
 // Occupancy is the design constraint: a wave stalls on its own LDS exchanges, so the kernel keeps three
-// waves per SIMD (<= 168 VGPRs, 48 KB of LDS per 4-wave block): the input is read straight from global
+// waves per SIMD (<= 168 VGPRs, 52 KB of LDS per 4-wave block): the input is read straight from global
 // memory (no block staging buffer), one of the three twiddle sets lives in a block-shared LDS table.
 //
 // Precision: FFT, power and mel sums in fp32; filter energies, log and DCT in
@@ -57,7 +56,7 @@ constexpr int kRingRows = 3 * kFramesPerWave;                // MFCC rows a wave
 constexpr int kRingBytes = kRingRows * kNCep * 4;
 constexpr int kDctBytes = kDctSteps * 64 * 8;                // block-shared B operands of the DCT matrix product
 constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes + kPowOffBytes;
-constexpr int kWavesPerSimd = 3;                             // register budget 168; three 48 KB blocks per CU
+constexpr int kWavesPerSimd = 3;                             // register budget 168; three 52 KB blocks per CU
 constexpr int kDeltaReach = 2;                               // delta(feat, 2) looks two rows to either side
 constexpr int kMaxRunFrames = 256;                           // frames one wave computes for one run, halo rows included
 constexpr int kLongRun = kMaxRunFrames - 2 * kDeltaReach;    // owned frames per run of a slice longer than kMaxRunFrames
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
     unsigned char* wbase = smem + wave * (kWaveLdsBytes + kRingBytes);
     float2* ex = reinterpret_cast<float2*>(wbase);                          // exchange 1 / 2, power spectrum
     float* en = reinterpret_cast<float*>(wbase + kExBytes);                  // [4 frames][32]
-    float* parts = reinterpret_cast<float*>(wbase + kExBytes + kEnBytes);   // [2][64]
+    float* parts = reinterpret_cast<float*>(wbase + kPartOffset);            // [2][64], inside the exchange region
     float* ring = reinterpret_cast<float*>(wbase + kWaveLdsBytes);           // [kRingRows][12]
     const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
     const double* dctb = reinterpret_cast<const double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
@@ -172,8 +171,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
                 const int j = fbase + it;
                 if (j >= last) break;
                 nfr = it + 1;
-                // (fetching the wave's next frame under the mel stage instead was measured slower: it costs
-                // 30 live registers and the third wave per SIMD already covers the load latency)
+                // (fetching the wave's next frame under the FFT instead was measured slower, with and without
+                // register spills: 18.3 -> 18.8 ms per 100 h at 130 registers)
                 RawFrame raw;
                 frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
                 if (it > 0) filter_sums(parts, en + (it - 1) * 32, K);      // the previous frame's, under this load
@@ -205,20 +204,19 @@ double mel2hz(double mel) { return 700.0 * (pow(10.0, mel / 2595.0) - 1.0); }
 void build_tables(MfccTables& t) {
     memset(&t, 0, sizeof(t));
     const double pi = 3.14159265358979323846;
-    for (int k1 = 1; k1 < 4; ++k1)
-        for (int b = 0; b < 4; ++b)
-            for (int l = 0; l < 64; ++l) {
-                const double a = -2.0 * pi * (double)((l + 64 * b) * k1) / 1024.0;
-                t.tw1[(k1 - 1) * 4 + b][l] = make_float2((float)cos(a), (float)sin(a));
-            }
-    for (int q1 = 1; q1 < 16; ++q1)
-        for (int c = 0; c < 16; ++c) {
-            const double a = -2.0 * pi * (double)(c * q1) / 256.0;
-            t.tw2[q1 - 1][c] = make_float2((float)cos(a), (float)sin(a));
+    for (int k1 = 1; k1 < 16; ++k1)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * pi * (double)(l * k1) / 1024.0;
+            t.tw1[k1 - 1][l] = make_float2((float)cos(a), (float)sin(a));
+        }
+    for (int q = 1; q < 16; ++q)
+        for (int a4 = 0; a4 < 4; ++a4) {
+            const double a = -2.0 * pi * (double)(a4 * q) / 64.0, sgn = a4 ? -1.0 : 1.0;
+            t.tw2[q - 1][a4] = make_float2((float)(sgn * cos(a)), (float)(sgn * sin(a)));
         }
     for (int j = 0; j < 8; ++j)
         for (int l = 0; l < 64; ++l) {
-            const double a = -2.0 * pi * (double)((l >> 4) + 4 * (l & 15) + 64 * j) / 2048.0;
+            const double a = -2.0 * pi * (double)fft_bin(l, j) / 2048.0;
             t.twr[j][l] = make_float2((float)cos(a), (float)sin(a));
         }
 
@@ -262,7 +260,7 @@ void build_tables(MfccTables& t) {
         if (t.run_count[63] == kRunSlot) abort();
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
-                const int k = (l >> 4) + 4 * (l & 15) + 64 * j;
+                const int k = fft_bin(l, j);
                 t.pow_off[0][l][j] = (unsigned short)(4 * slot_of[k]);
                 t.pow_off[1][l][j] = (unsigned short)(4 * slot_of[1024 - k]);
             }

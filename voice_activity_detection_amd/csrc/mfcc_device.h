@@ -15,19 +15,17 @@ constexpr int kNCep = VAD_NUM_CEPS;           // 12
 constexpr int kFramesPerWave = 4;              // frames whose log/DCT tail a wave batches
 constexpr int kMaxRun = 20;                   // bins per lane in the mel stage
 constexpr int kDctSteps = 7;                  // k-steps of 4 covering the 26 filters in the DCT matrix product
-constexpr int kEx1Stride = 272;               // exchange 1: complex elements per k1 row (256 + 16: the two
-                                              // k1 rows of a 32-lane half land on opposite bank halves)
-constexpr int kEx2Plane = 272;                // exchange 2: complex elements per k1 plane (16 rows of 17): the two
-                                              // planes of a 32-lane half interleave on the 64 banks
-constexpr int kExBytes = 8704;                // = 4*272*8 >= (3*272 + 15*17 + 16)*8, >= 1024*8
+constexpr int kExStride = 68;                 // the exchange: complex elements per k1 row (64 + 4: the eight k1 rows that
+                                              // the lanes of a 32-lane half read land 8 banks apart)
+constexpr int kExBytes = 16 * kExStride * 8;  // 8704
 constexpr int kRunSlot = 20;                  // power spectrum in LDS: the run of mel lane l occupies floats [20 l, 20 l + 20),
                                               // so the lanes' 16-byte reads of their runs fall on distinct banks
 constexpr int kPowFloats = 64 * kRunSlot;
 
 struct MfccTables {
-    float2 tw1[12][64];      // [(k1-1)*4 + b][lane]  W1024^((lane + 64 b) * k1)
-    float2 tw2[15][16];      // [q1-1][c]             W256^(c * q1)
-    float2 twr[8][64];       // [jj][lane]            W2048^(k1 + 4 q1 + 64 jj), lane = 16 k1 + q1
+    float2 tw1[15][64];      // [k1-1][lane]          W1024^(lane * k1)
+    float2 tw2[15][4];       // [q-1][a]              s_a W64^(a * q), s = (1, -1, -1, -1): the signs pass C expects
+    float2 twr[8][64];       // [u][lane]             W2048^k, k = fft_bin(lane, u)
     int run_start[64];       // mel stage: first bin of the lane's run
     int run_count[64];       //            bins in the run (0 for idle lanes)
     int run_b0[64];          //            first bin of the run's segment
@@ -41,9 +39,20 @@ struct MfccTables {
     double dctb[kDctSteps][64];  // the same matrix as B operands of v_mfma_f64_16x16x4_f64: step s, lane l holds
                                  // dct[4 s + (l >> 4)][l & 15], zero outside 26 x 12
     unsigned short pow_off[2][64][8];   // byte offset, inside the power-spectrum image, of the bins FFT lane l produces:
-                                        // [0][l][jj] bin k = (l >> 4) + 4 (l & 15) + 64 jj, [1][l][jj] bin 1024 - k
-    int pow_off_512;                    // the same for bin 512 (lane 0's self-paired bin)
+                                        // [0][l][u] bin k = fft_bin(l, u), [1][l][u] bin 1024 - k
+    int pow_off_512;                    // the same for bin 512 (lane 1's self-paired bin)
 };
+
+// After pass C lane l = 4 k1 + a holds Z[k1 + 16 q + 256 rev(a)] in register q (rev = 0, 2, 1, 3).  The untangle
+// pairs it with Z[1024 - k]; slot u of a lane is the pair it works on in step u: register u and its partner
+// (register 15 - u of lane 4 (16 - k1) + 3 - a; for k1 = 0 register 16 - u of lane 3 - a).  Step 0 of lanes 0..3
+// takes what that rule leaves over: lane 0 bins 0 / 1024 (register 0, self-paired), lane 2 bins 256 / 768 (register
+// 0, partner lane 3), lanes 1 and 3 register 8 (bins 640 / 384 with lane 2, bins 896 / 128 with lane 0).
+__host__ __device__ inline int fft_bin(int lane, int u) {
+    const int k1 = lane >> 2, a = lane & 3, rev = ((a & 1) << 1) | (a >> 1);
+    if (k1 == 0 && u == 0 && (a & 1)) return 128 + 256 * rev;
+    return k1 + 16 * u + 256 * rev;
+}
 
 static_assert(offsetof(MfccTables, pow_off) % 16 == 0 && offsetof(MfccTables, dctb) % 8 == 0,
               "tables that are copied to LDS in 16-byte pieces");
@@ -117,22 +126,24 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 
-// Per-wave LDS: [exchange 1 / 2, then power spectrum, then log energies][filter energies of 4 frames][2 x 64 mel
-// partial sums of the last frame: outside the exchange region, they are summed while the next frame loads]
+// Per-wave LDS: [the exchange, then power spectrum | 2 x 64 mel partial sums, then log energies][filter energies
+// of 4 frames].  The partial sums of a frame sit behind its power spectrum and are summed while the next frame
+// loads, before that frame's exchange overwrites them.
 constexpr int kEnBytes = kFramesPerWave * 32 * 4;
 constexpr int kPartBytes = 2 * 64 * 4;
-constexpr int kWaveLdsBytes = kExBytes + kEnBytes + kPartBytes;
-static_assert(kPowFloats * 4 <= kExBytes, "the power spectrum must fit the exchange region");
+constexpr int kPartOffset = kPowFloats * 4;
+constexpr int kWaveLdsBytes = kExBytes + kEnBytes;
+static_assert(kPartOffset + kPartBytes <= kExBytes, "the power spectrum and the partial sums must fit the exchange region");
 
-// Block-shared LDS image of the W1024 twiddles tw1[12][64] (the head of MfccTables); the other two sets
+// Block-shared LDS image of the W1024 twiddles tw1[15][64] (the head of MfccTables); the other two sets
 // live in registers.
-constexpr int kTwFloat2s = 12 * 64;
+constexpr int kTwFloat2s = 15 * 64;
 constexpr int kPowOffBytes = 2 * 64 * 8 * 2;   // block-shared LDS image of MfccTables::pow_off
 
 // Loop-invariant per-lane constants that stay in registers (the twiddles do not: see frame_energies).
 struct LaneConst {
-    float2 tw2[15];                           // W256^(c q1) of this lane's c  } the twiddle sets that fit the
-    float2 twr[8];                            // W2048^(k1 + 4 q1 + 64 jj)       } registers at 3 waves per SIMD
+    float2 tw2[15];                           // s_a W64^(a q) of this lane's a  } the twiddle sets that fit the
+    float2 twr[8];                            // W2048^fft_bin(lane, u)          } registers at 3 waves per SIMD
     int run_count;
     float run_inv, run_w0, run_f0;
     int rise_first, rise_n, fall_first, fall_n;
@@ -140,7 +151,7 @@ struct LaneConst {
 
 __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* __restrict__ tab, int lane) {
 #pragma unroll
-    for (int k = 0; k < 15; ++k) K.tw2[k] = tab->tw2[k][lane & 15];
+    for (int k = 0; k < 15; ++k) K.tw2[k] = tab->tw2[k][lane & 3];
 #pragma unroll
     for (int j = 0; j < 8; ++j) K.twr[j] = tab->twr[j][lane];
     const int run_start = tab->run_start[lane];
@@ -189,8 +200,8 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, const u32x4* pow_off, int off512,
                                                const LaneConst& K, float2* ex, float* parts) {
     const int lane = fresh_lane();
-    const int k1l = lane >> 4, q1l = lane & 15;
-    float* pw = reinterpret_cast<float*>(ex);                               // aliases ex once exchange 2 is read
+    const int k1l = lane >> 2, al = lane & 3;
+    float* pw = reinterpret_cast<float*>(ex);                               // aliases ex once the exchange is read
 
     // ---- pre-emphasis: z[n] = y[2n] + i y[2n+1], n = lane + 64 jj ----
     float2 v[16];
@@ -203,69 +214,109 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     }
     v[15] = make_float2(0.0f, 0.0f);                        // samples 1920..2047 are zero padding
 
-    // ---- pass A: radix 4 over n1 = jj >> 2; outputs k1 land in v[4 k1 + b] ----
+    // ---- pass A: radix 16 over jj in registers; register k1 then holds sub-transform k1 of point n2 = lane;
+    //      twiddle W1024^(n2 k1) ----
+    dft16(v);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) dft4(v[b], v[4 + b], v[8 + b], v[12 + b]);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) v[4 + k] = cmul(v[4 + k], tws[k * 64 + lane]);
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tws[(k - 1) * 64 + lane]);
 
-    // ---- exchange 1: [k1][n2 = lane + 64 b] -> lane (k1, c) reads n2 = c + 16 m ----
+    // ---- the exchange: [k1][n2] -> lane (k1, a) reads n2 = a + 4 b, b = 0..15 ----
 #pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) ex[k1 * kEx1Stride + lane + 64 * b] = v[4 * k1 + b];
+    for (int k1 = 0; k1 < 16; ++k1) ex[k1 * kExStride + lane] = v[k1];
     wave_lds_fence();
     {
-        const float2* rd = ex + k1l * kEx1Stride + q1l;
+        const float2* rd = ex + k1l * kExStride + al;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = rd[16 * m];
+        for (int b = 0; b < 16; ++b) v[b] = rd[4 * b];
     }
     wave_lds_fence();
 
-    // ---- pass B: radix 16 over m; twiddle W256^(c q1) ----
+    // ---- pass B: radix 16 over b -> q; twiddle W64^(a q), with the signs pass C expects (tw2) ----
     dft16(v);
+    {
+        const float s0 = al ? -1.0f : 1.0f;
+        v[0] = make_float2(v[0].x * s0, v[0].y * s0);
+    }
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], K.tw2[k - 1]);
 
-    // ---- exchange 2: [k1][q1][c] -> lane (k1, q1) reads c = 0..15 ----
+    // ---- pass C: radix 4 over a, across the four lanes of a quad (DPP operands, no LDS).  With x_a the
+    //      twiddled values (lanes 1..3 hold them negated):
+    //        stage 1 (partner a ^ 2)   r = x + c1 P:   lane 0 x0 + x2, lane 1 -(x1 + x3), lane 2 x0 - x2, lane 3 x1 - x3
+    //        lane 3 turns its value by i
+    //        stage 2 (partner a ^ 1)   X = r + c2 P:   lane 0 X0, lane 1 X2, lane 2 X1, lane 3 X3
+    //      so lane (k1, a) ends up with Z[k1 + 16 q + 256 rev(a)] in register q. ----
     {
-        float2* wr = ex + k1l * kEx2Plane + q1l;
+        const float c1 = ((al + 1) & 2) ? 1.0f : -1.0f;     // -1, 1, 1, -1
+        const float c2 = (al & 1) ? 1.0f : -1.0f;           // -1, 1, -1, 1
+        const bool turn = al == 3;
+        // r += c * (r of the quad partner): one v_fmac_f32 whose first operand is fetched through DPP.  Eight at a
+        // time in one asm statement: the two wait states a DPP read needs after a vector write of the same
+        // register are paid once per statement (the compiler does not track hazards into inline asm), and the
+        // eight instructions touch eight different registers.
+#define VAD_QUAD_FMAC8(CTRL, R)                                                                                  \
+        asm volatile("s_nop 1\n\t"                                                                                \
+                     "v_fmac_f32_dpp %0, %0, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                           \
+                     "v_fmac_f32_dpp %1, %1, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                           \
+                     "v_fmac_f32_dpp %2, %2, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                           \
+                     "v_fmac_f32_dpp %3, %3, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                           \
+                     "v_fmac_f32_dpp %4, %4, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                           \
+                     "v_fmac_f32_dpp %5, %5, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                           \
+                     "v_fmac_f32_dpp %6, %6, %8 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                           \
+                     "v_fmac_f32_dpp %7, %7, %8 " CTRL " row_mask:0xf bank_mask:0xf"                                \
+                     : "+v"(R[0].x), "+v"(R[0].y), "+v"(R[1].x), "+v"(R[1].y), "+v"(R[2].x), "+v"(R[2].y),       \
+                       "+v"(R[3].x), "+v"(R[3].y)                                                                \
+                     : "v"(cc))
 #pragma unroll
-        for (int q = 0; q < 16; ++q) wr[17 * q] = v[q];
-    }
-    wave_lds_fence();
-    {
-        const float2* rd = ex + k1l * kEx2Plane + 17 * q1l;
+        for (int g = 0; g < 4; ++g) {
+            float2* r = v + 4 * g;
+            float cc = c1;
+            VAD_QUAD_FMAC8("quad_perm:[2,3,0,1]", r);
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = rd[c];
+            for (int q = 0; q < 4; ++q) {
+                const float rx = r[q].x, ry = r[q].y;
+                r[q] = make_float2(turn ? -ry : rx, turn ? rx : ry);
+            }
+            cc = c2;
+            VAD_QUAD_FMAC8("quad_perm:[1,0,3,2]", r);
+        }
+#undef VAD_QUAD_FMAC8
     }
-    wave_lds_fence();
 
-    // ---- pass C: radix 16 over c; register q2 now holds Z[k1 + 4 q1 + 64 q2] ----
-    dft16(v);
-
-    // ---- real-input untangle on the pairs (k, 1024 - k), k = k1 + 4 q1 + 64 jj < 512:
-    //      with E = Z[k] + conj(Z[N-k]), O = Z[k] - conj(Z[N-k]), T = W2048^k O,
-    //      4 |X[k]|^2 = |E - iT|^2 and 4 |X[N-k]|^2 = |E + iT|^2.
-    //      Z[1024 - k] is register 15 - jj of lane `plane` (a cross-lane read, no LDS image of Z);
-    //      lane 0 holds the bins 64 q2, whose partners 64 (16 - q2) are its own registers. ----
-    const int plane = k1l ? 16 * (4 - k1l) + 15 - q1l : (q1l ? 16 - q1l : 0);
-    const int paddr = plane * 4;
+    // ---- real-input untangle on the pairs (k, 1024 - k) (fft_bin: which pair a lane takes in step u):
+    //      with a = Z[k], b = Z[1024 - k], E = a + conj(b), O = a - conj(b), T = W2048^k O,
+    //      4 |X[k]|^2 = |E - iT|^2 and 4 |X[1024 - k]|^2 = |E + iT|^2.
+    //      b is a register of another lane (a cross-lane read, no LDS image of Z): the SENDER picks the register
+    //      its reader wants in step u. ----
+    const bool zl = k1l == 0;                                                // lanes 0..3: the bins with k1 = 0
+    const int plane = zl ? 3 - al : 4 * (16 - k1l) + 3 - al;
+    const int plane0 = zl ? (((al + 1) & 2) ? al + 1 : 0) : plane;            // step 0 of lanes 0..3: 0, 2, 3, 0
+    const int paddr = plane * 4, paddr0 = plane0 * 4;
     const u32x4 off_lo = pow_off[lane], off_hi = pow_off[64 + lane];       // 8 + 8 packed 16-bit byte offsets
     unsigned char* pwb = reinterpret_cast<unsigned char*>(pw);
     // all sixteen cross-lane reads are issued ahead of their use: their latency is paid once
     float2 partner[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        partner[u].x = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(v[15 - u].x)));
-        partner[u].y = __int_as_float(__builtin_amdgcn_ds_bpermute(paddr, __float_as_int(v[15 - u].y)));
+        float2 send;
+        if (u == 0) {
+            const float2 s0 = al == 3 ? v[0] : v[8];
+            send = zl ? s0 : v[15];
+        } else {
+            send = zl ? v[16 - u] : v[15 - u];
+        }
+        partner[u].x = __int_as_float(__builtin_amdgcn_ds_bpermute(u ? paddr : paddr0, __float_as_int(send.x)));
+        partner[u].y = __int_as_float(__builtin_amdgcn_ds_bpermute(u ? paddr : paddr0, __float_as_int(send.y)));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
-        const float2 a = v[jj];
+        float2 a = v[jj];
         float2 b = partner[jj];
-        if (lane == 0) b = v[(16 - jj) & 15];
+        if (jj == 0) {
+            if (zl && (al & 1)) a = v[8];
+            if (lane == 0) b = v[0];
+        }
         const float2 e = make_float2(a.x + b.x, a.y - b.y);
         const float2 o = make_float2(a.x - b.x, a.y + b.y);
         const float2 t = cmul(K.twr[jj], o);
@@ -276,8 +327,8 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         *reinterpret_cast<float*>(pwb + o_lo) = (ar * ar + ai * ai) * (0.25f / 2048.0f);      // bin k
         *reinterpret_cast<float*>(pwb + o_hi) = (br * br + bi * bi) * (0.25f / 2048.0f);      // bin 1024 - k
     }
-    if (lane == 0)                                                                             // the self-paired bin 512
-        *reinterpret_cast<float*>(pwb + off512) = (v[8].x * v[8].x + v[8].y * v[8].y) * (1.0f / 2048.0f);
+    if (lane == 1)                                                                             // the self-paired bin 512
+        *reinterpret_cast<float*>(pwb + off512) = (v[0].x * v[0].x + v[0].y * v[0].y) * (1.0f / 2048.0f);
     wave_lds_fence();
 
     // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the lane reads
