@@ -1,4 +1,4 @@
-// How many cycles does a SIMD spend per wave64 v_fma_f32 when 1, 2 or 4 waves share it?
+// How many cycles does a SIMD spend per wave64 v_fma_f32 / v_add_f32 / v_fmac_f32 when 1, 2, 3 or 4 waves share it?
 // One block per CU (100 KB of dynamic LDS keeps a second block out), block = 256 / 512 / 1024 threads.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -11,8 +11,17 @@ __global__ void probe(float* out, int iters, float a, float b) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             // inline asm keeps the compiler from pairing these into v_pk_fma_f32
+            if (MFMA == 0)
             asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
                          "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+            else if (MFMA == 1)                      // VOP2 add
+            asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+            else                                     // VOP2 fmac
+            asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n"
+                         "v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9"
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
         }
     }
@@ -24,18 +33,23 @@ int main() {
     float* out;
     hipMalloc(&out, 256 * 1024 * sizeof(float));
     hipFuncSetAttribute((const void*)probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void*)probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void*)probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;                       // 64 FMAs per iteration per wave
-    for (int threads : {256, 512, 1024}) {
+    for (int op = 0; op < 3; ++op)
+    for (int threads : {256, 512, 768, 1024}) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL(probe<0>, dim3(256), dim3(threads), 100 * 1024, 0, out, iters, 1.0001f, 0.5f);
+            if (op == 0) hipLaunchKernelGGL(probe<0>, dim3(256), dim3(threads), 100 * 1024, 0, out, iters, 1.0001f, 0.5f);
+            if (op == 1) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(threads), 100 * 1024, 0, out, iters, 1.0001f, 0.5f);
+            if (op == 2) hipLaunchKernelGGL(probe<2>, dim3(256), dim3(threads), 100 * 1024, 0, out, iters, 1.0001f, 0.5f);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double inst_per_simd = (double)iters * 64 * (threads / 256);
-            printf("waves/SIMD %d  %.3f ms  %.2f ns per wave-instruction per SIMD (x clock GHz = cycles)\n", threads / 256, ms,
+            printf("%s waves/SIMD %d  %.3f ms  %.2f ns per wave-instruction per SIMD (x clock GHz = cycles)\n", op == 0 ? "v_fma_f32 (VOP3)" : op == 1 ? "v_add_f32 (VOP2)" : "v_fmac_f32 (VOP2)", threads / 256, ms,
                    ms * 1e6 / inst_per_simd);
         }
     }
