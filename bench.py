@@ -36,6 +36,7 @@ PEAK_BF16_TFLOPS = 2500.0         # dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
 SIMDS = 256 * 4
 VALU_ISSUE_CYCLES = 2.0           # a wave64 vector instruction occupies its SIMD-32 for 2 cycles
+VALU_ISSUE_NS_MEASURED = 1.18                  # ns per wave64 v_add_f32 per SIMD with three waves on it (probe)
 FRONTEND_BYTES_PER_FRAME = 480 * 2 + 24 * 4          # int16 in, 24 floats out
 FRONTEND_FLOP_PER_FRAME = 64_000                       # 2048-pt rfft + power + mel + DCT + delta
 RESULT_BYTES_PER_WINDOW = 9                            # 2 float posteriors + 1 decision byte
@@ -409,9 +410,14 @@ def main():
         if fe_pmc and 'valu_insts_per_unit' in fe_pmc:
             # the time the chip needs just to ISSUE the kernel's vector instructions at 2.4 GHz
             issue_ms = fe_pmc['valu_insts_per_unit'] * n_frames * VALU_ISSUE_CYCLES / (SIMDS * 2.4e9) * 1e3
+            # the same at the rate a SIMD sustains on independent v_add_f32 / v_fmac_f32 with the kernel's three
+            # waves per SIMD (tools/probes/valu_issue_probe.hip, profiles/r02_valu_issue_probe.txt)
+            measured_ms = fe_pmc['valu_insts_per_unit'] * n_frames * VALU_ISSUE_NS_MEASURED / SIMDS * 1e-6
             fe_roof['valu_issue'] = {'valu_wave_insts_per_frame': fe_pmc['valu_insts_per_unit'],
                                      'cycles_per_inst': VALU_ISSUE_CYCLES, 'bound_ms': issue_ms,
-                                     'frac': issue_ms / fe_ms}
+                                     'frac': issue_ms / fe_ms,
+                                     'measured_ns_per_inst': VALU_ISSUE_NS_MEASURED, 'measured_bound_ms': measured_ms,
+                                     'measured_frac': measured_ms / fe_ms}
         rec = {
             'value': value, 'unit': 'audio-hours/s', 'steps': steps, 'warmup': warmup,
             'ms_per_step': elapsed / steps * 1e3,
