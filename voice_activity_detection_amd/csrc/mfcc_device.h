@@ -21,6 +21,7 @@ constexpr int kExBytes = 16 * kExStride * 8;  // 8704
 constexpr int kRunSlot = 20;                  // power spectrum in LDS: the run of mel lane l occupies floats [20 l, 20 l + 20),
                                               // so the lanes' 16-byte reads of their runs fall on distinct banks
 constexpr int kPowFloats = 64 * kRunSlot;
+constexpr float kPowScale = 0.25f / 2048.0f;  // 2^-13
 
 struct MfccTables {
     float2 tw1[15][64];      // [k1-1][lane]          W1024^(lane * k1)
@@ -157,9 +158,12 @@ __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* 
     const int run_start = tab->run_start[lane];
     K.run_count = tab->run_count[lane];
     const float b0 = (float)tab->run_b0[lane], b1 = (float)tab->run_b1[lane];
-    K.run_inv = tab->run_inv[lane];
-    K.run_w0 = ((float)run_start - b0) * K.run_inv;        // rising weight of the run's first bin
-    K.run_f0 = (b1 - (float)run_start) * K.run_inv;        // falling weight of the run's first bin
+    // The power spectrum is left unscaled in LDS, 4 nfft |X|^2 / nfft = 2^13 times psf's |X|^2 / nfft; the mel
+    // weights carry the 2^-13 instead (a power of two: the same bits as scaling every bin, one multiply less per bin)
+    const float inv = tab->run_inv[lane];
+    K.run_inv = inv * kPowScale;
+    K.run_w0 = ((float)run_start - b0) * inv * kPowScale;  // rising weight of the run's first bin
+    K.run_f0 = (b1 - (float)run_start) * inv * kPowScale;  // falling weight of the run's first bin
     const int fl = lane < kNFilt ? lane : 0;
     K.rise_first = tab->rise_first[fl];
     K.rise_n = tab->rise_n[fl];
@@ -324,11 +328,11 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         const float br = e.x - t.y, bi = e.y + t.x;                       // E + iT
         const unsigned wl = off_lo[jj >> 1], wh = off_hi[jj >> 1];
         const unsigned o_lo = (jj & 1) ? wl >> 16 : wl & 0xFFFFu, o_hi = (jj & 1) ? wh >> 16 : wh & 0xFFFFu;
-        *reinterpret_cast<float*>(pwb + o_lo) = (ar * ar + ai * ai) * (0.25f / 2048.0f);      // bin k
-        *reinterpret_cast<float*>(pwb + o_hi) = (br * br + bi * bi) * (0.25f / 2048.0f);      // bin 1024 - k
+        *reinterpret_cast<float*>(pwb + o_lo) = ar * ar + ai * ai;                            // bin k (x 2^13)
+        *reinterpret_cast<float*>(pwb + o_hi) = br * br + bi * bi;                            // bin 1024 - k
     }
     if (lane == 1)                                                                             // the self-paired bin 512
-        *reinterpret_cast<float*>(pwb + off512) = (v[0].x * v[0].x + v[0].y * v[0].y) * (1.0f / 2048.0f);
+        *reinterpret_cast<float*>(pwb + off512) = (v[0].x * v[0].x + v[0].y * v[0].y) * 4.0f;
     wave_lds_fence();
 
     // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the lane reads
