@@ -134,11 +134,30 @@ struct ActView {
 // REG_FROM.. stay in registers instead of LDS: the lane halves split the input channels by parity, so a growth
 // channel is only ever read by one half, and gr[s][l] holds relative channel G REG_FROM + 2 s + half at position l
 // (G REG_FROM even).  With REG_FROM = NL everything goes to LDS.
-template <int NL, int G, int L, int REG_FROM>
+//
+// STAGED: the weights (in global memory) reach the FMAs through `ring`, 256 floats of LDS private to the wave.
+// Every lane of a wave needs the same twelve weights per channel; read straight from global memory that is three
+// 16-byte loads per channel whose ~1 000 cycles of latency two waves per SIMD cannot cover (and there are no
+// registers to request more channels ahead).  Instead one coalesced 16-byte load per LANE fetches a chunk of 20
+// channels (+ the 16 floats behind them: the layer's shift row when the chunk is its last) a whole chunk ahead of
+// its use, four registers in flight; when the channel loop reaches the chunk it is written to the ring and read
+// back as broadcasts.  The values and the order of the arithmetic are those of the direct reads.
+constexpr int kStageChannels = 20;
+constexpr int kStageFloats = 256;
+
+template <int NL, int G, int L, int REG_FROM, bool STAGED = false>
 __device__ __forceinline__ void dense_block(const ActView& v, const float* block_w, int c_first, int half,
-                                            float (&gr)[((NL - REG_FROM) * G + 1) / 2 + 1][L]) {
+                                            float (&gr)[((NL - REG_FROM) * G + 1) / 2 + 1][L], float* ring = nullptr) {
     static_assert((G * REG_FROM) % 2 == 0, "the register-resident channels start at an even channel");
+    static_assert(!STAGED || G % 2 == 0, "staged weights: every layer starts on an even channel");
     constexpr int kRegFirst = G * REG_FROM;                       // first relative channel kept in registers
+    int ring_base = 0;                                            // first channel of the chunk in the ring (wave-uniform)
+    float4 pre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);             // the lane's 16 bytes of the chunk after that
+    int stage_lane = 0;
+    if constexpr (STAGED) {
+        stage_lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        pre = *reinterpret_cast<const float4*>(block_w + 4 * stage_lane);
+    }
     if constexpr (REG_FROM < NL) {
 #pragma unroll
         for (int s2 = 0; s2 < ((NL - REG_FROM) * G + 1) / 2; ++s2)
@@ -149,13 +168,26 @@ __device__ __forceinline__ void dense_block(const ActView& v, const float* block
     for (int layer = 0; layer < NL; ++layer) {                    // unrolled: the channel count below is a constant
         const int cin = c_first + G * layer;
         const float* wl = block_w + dense_layer_offset(c_first, G, layer);
+        // (staged) the chunk that starts at channel `base` of this layer moves from `pre` into the ring, and the
+        // chunk after it -- the next layer's first one behind this layer's last -- is requested
+        auto install = [&](int base) {
+            wave_lds_fence();                                     // the reads of the chunk it replaces
+            reinterpret_cast<float4*>(ring)[stage_lane] = pre;
+            wave_lds_fence();
+            ring_base = base;
+            const float* nxt = base + kStageChannels < cin
+                                   ? wl + (base + kStageChannels) * 12
+                                   : block_w + dense_layer_offset(c_first, G, layer + 1 < NL ? layer + 1 : layer);
+            pre = *reinterpret_cast<const float4*>(nxt + 4 * stage_lane);
+        };
         float acc[G][L];
 #pragma unroll
         for (int o = 0; o < G; ++o)
 #pragma unroll
             for (int l = 0; l < L; ++l) acc[o][l] = 0.0f;
         auto accumulate = [&](int c, const float (&a)[L]) {
-            const float4* wp = reinterpret_cast<const float4*>(wl + c * 12);
+            const float4* wp = STAGED ? reinterpret_cast<const float4*>(ring + (c - ring_base) * 12)
+                                      : reinterpret_cast<const float4*>(wl + c * 12);
             const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2];
             const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
 #pragma unroll
@@ -177,28 +209,45 @@ __device__ __forceinline__ void dense_block(const ActView& v, const float* block
         // The lane halves take the even / the odd channels (c_first is even, so both halves leave the first
         // range together).  The weight loads of several channels have to be in flight at once: the unrolled
         // iterations are independent until the accumulation.
-#pragma unroll 4
-        for (int c = half; c < c_first; c += 2) channel(c, v.a + c * v.a_c, v.a_l);
         const int lds_end = layer < REG_FROM ? cin : c_first + kRegFirst;   // growth channels that live in LDS
+        const int n_reg = (REG_FROM < NL && layer > REG_FROM) ? (layer - REG_FROM) * G : 0;   // register-resident inputs
+        // the channels [lo, hi) of this layer, in order: stem / transition outputs, growth channels in LDS, in registers
+        auto channels = [&](int lo, int hi) {
+            const int hi_a = hi < c_first ? hi : c_first;
 #pragma unroll 4
-        for (int c = c_first + half; c < lds_end; c += 2) channel(c, v.b + (c - c_first) * v.b_c, v.b_l);
-        if constexpr (REG_FROM < NL) {
-            const int n_reg = layer > REG_FROM ? (layer - REG_FROM) * G : 0;     // register-resident inputs of this layer
+            for (int c = lo + half; c < hi_a; c += 2) channel(c, v.a + c * v.a_c, v.a_l);
+            const int lo_b = lo > c_first ? lo : c_first, hi_b = hi < lds_end ? hi : lds_end;
+#pragma unroll 4
+            for (int c = lo_b + half; c < hi_b; c += 2) channel(c, v.b + (c - c_first) * v.b_c, v.b_l);
+            if constexpr (REG_FROM < NL) {
 #pragma unroll
-            for (int s2 = 0; s2 < (n_reg + 1) / 2; ++s2) {
-                if (2 * s2 + 1 < n_reg) {
-                    accumulate(c_first + kRegFirst + 2 * s2 + half, gr[s2]);
-                } else {
-                    // the odd channel of the last pair does not exist yet: the upper half multiplies zeros (by the
-                    // rows that follow in the weight table: finite values)
-                    float a[L];
+                for (int s2 = 0; s2 < (n_reg + 1) / 2; ++s2) {
+                    const int ce = c_first + kRegFirst + 2 * s2;
+                    if (ce < lo || ce >= hi) continue;
+                    if (2 * s2 + 1 < n_reg) {
+                        accumulate(ce + half, gr[s2]);
+                    } else {
+                        // the odd channel of the last pair does not exist yet: the upper half multiplies zeros (by
+                        // the rows that follow in the weight table: finite values)
+                        float a[L];
 #pragma unroll
-                    for (int l = 0; l < L; ++l) a[l] = half ? 0.0f : gr[s2][l];
-                    accumulate(c_first + kRegFirst + 2 * s2 + half, a);
+                        for (int l = 0; l < L; ++l) a[l] = half ? 0.0f : gr[s2][l];
+                        accumulate(ce + half, a);
+                    }
                 }
             }
+        };
+        if constexpr (STAGED) {
+#pragma unroll
+            for (int base = 0; base < cin; base += kStageChannels) {
+                install(base);
+                channels(base, base + kStageChannels < cin ? base + kStageChannels : cin);
+            }
+        } else {
+            channels(0, cin);
         }
-        const float4 sh4 = *reinterpret_cast<const float4*>(wl + cin * 12);
+        const float4 sh4 = STAGED ? *reinterpret_cast<const float4*>(ring + (cin - ring_base) * 12)
+                                  : *reinterpret_cast<const float4*>(wl + cin * 12);
         const float sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
         if (layer < REG_FROM) {
 #pragma unroll
@@ -283,18 +332,19 @@ __device__ __forceinline__ void stem_single(const float* x_row, const float* __r
 // private array act2[c][2][32] (which may alias v1's growth region), dense block 2, cnn_out, Linear, softmax.
 // `dense_w[b]` points at the growth-layer weights of dense block b (the blob's, or a copy in LDS).
 // REG1 / REG2: first growth layer of dense block 1 / 2 whose outputs stay in registers (D::nl = none).
-template <bool LARGE, int REG1 = Dims<LARGE>::nl, int REG2 = Dims<LARGE>::nl>
+// STAGED / ring: see dense_block.
+template <bool LARGE, int REG1 = Dims<LARGE>::nl, int REG2 = Dims<LARGE>::nl, bool STAGED = false>
 __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, const float* __restrict__ blob,
                                               const float* dense_w0, const float* dense_w1,
                                               const DnLayout& LY, int lane, long w, long n_windows,
                                               float* __restrict__ p_out, uint8_t* __restrict__ dec_out, int mode,
-                                              float threshold) {
+                                              float threshold, float* ring = nullptr) {
     using D = Dims<LARGE>;
     const int half = lane >> 5, col = lane & 31;
 
     // ---- dense block 1 (5 positions) ----
     float gr1[((D::nl - REG1) * D::g + 1) / 2 + 1][kL1];
-    dense_block<D::nl, D::g, kL1, REG1>(v1, dense_w0, D::c0, half, gr1);
+    dense_block<D::nl, D::g, kL1, REG1, STAGED>(v1, dense_w0, D::c0, half, gr1, ring);
     constexpr int kSReg1 = (D::c0 + D::g * REG1) / 2;           // first k-step of the 1x1 convolution fed from gr1
 
     // ---- transition: 1x1 conv c1 -> c0 + BN + MaxPool(2) + LeakyReLU, 5 -> 2 (position 4 is dropped) ----
@@ -345,7 +395,7 @@ __device__ __forceinline__ void densenet_tail(const ActView& v1, float* act2, co
     // ---- dense block 2 (2 positions) ----
     const ActView v2{act2 + col, kL2 * 32, 32, act2 + D::c0 * kL2 * 32 + col, kL2 * 32, 32, D::c0};
     float gr2[((D::nl - REG2) * D::g + 1) / 2 + 1][kL2];
-    dense_block<D::nl, D::g, kL2, REG2>(v2, dense_w1, D::c0, half, gr2);
+    dense_block<D::nl, D::g, kL2, REG2, STAGED>(v2, dense_w1, D::c0, half, gr2, ring);
     constexpr int kSReg2 = (D::c0 + D::g * REG2) / 2;
 
     // ---- cnn_out: 1x1 conv c1 -> c1 + BN + MaxPool(2) + LeakyReLU, 2 -> 1; then Linear(c1 -> 2) ----
@@ -434,10 +484,12 @@ struct DnStreamCfg {
     // SIMD (large) share a CU
     static constexpr int reg1 = D::reg1, reg2 = D::reg2, priv = D::priv;
     // The growth-layer weights of both dense blocks are read once per channel by every wave, two addresses
-    // per wave-instruction: the small model keeps a block-shared copy in LDS (the large model's LDS is full).
+    // per wave-instruction: the small model keeps a block-shared copy in LDS; the large model's LDS has no room
+    // for one (47 KB), so its waves stage the weights chunk by chunk through 1 KB each (dense_block, STAGED).
     static constexpr bool dense_in_lds = !LARGE;
+    static constexpr bool dense_staged = LARGE;
     // (+ 16 floats: a layer whose register-resident inputs end on an even channel reads one row past its weights)
-    static constexpr int dense_floats = dense_in_lds ? 2 * dense_layer_offset(D::c0, D::g, D::nl) + 16 : 0;
+    static constexpr int dense_floats = dense_in_lds ? 2 * dense_layer_offset(D::c0, D::g, D::nl) + 16 : waves * kStageFloats;
     static_assert(waves * priv >= D::c0 * rows, "the S image of phase 1 fits the private regions it aliases");
     static constexpr int lds_floats = D::c0 * rows + waves * priv + dense_floats;
 };
@@ -508,7 +560,8 @@ __global__ __launch_bounds__(DnStreamCfg<LARGE>::waves * 64) void densenet_strea
     const ActView v1{M + ml, C::rows, 2, priv + col, kL1 * 32, 32, D::c0};
     const float* dw0 = C::dense_in_lds ? dense_lds : blob + LY.dense[0];
     const float* dw1 = C::dense_in_lds ? dense_lds + dense_layer_offset(D::c0, D::g, D::nl) : blob + LY.dense[1];
-    densenet_tail<LARGE, C::reg1, C::reg2>(v1, priv, blob, dw0, dw1, LY, lane, w, n_windows, p_out, dec_out, mode, threshold);
+    densenet_tail<LARGE, C::reg1, C::reg2, C::dense_staged>(v1, priv, blob, dw0, dw1, LY, lane, w, n_windows, p_out, dec_out, mode,
+                                                            threshold, dense_lds + wave * kStageFloats);
 }
 
 // ---------------------------------------------------------------------------------------------
