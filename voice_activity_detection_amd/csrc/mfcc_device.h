@@ -193,10 +193,9 @@ __device__ __forceinline__ void frame_load(RawFrame& raw, const int* __restrict_
 
 // One frame from its raw input to the mel partial sums of the 64 run-lanes in parts[0..63] (rising edges) and
 // parts[64..127] (falling edges); filter_sums turns them into the 26 filter energies.
-// The twiddle factors are read from `tws`, a block-shared LDS image of the tables, where they are used
-// instead of living in ~70 registers: the kernel is latency-bound (in-order waves stalling on their own
-// LDS exchanges), three waves per SIMD need the register file, and reading them from global memory
-// instead makes the kernel texture-path-bound (measured 2.2x slower).
+// The W1024 twiddle factors are read from `tws`, a block-shared LDS image of the table, where they are used
+// instead of living in 30 registers: three waves per SIMD need the register file, and reading them from
+// global memory instead makes the kernel texture-path-bound (measured 2.2x slower).
 // `pow_off` is the block's LDS copy of MfccTables::pow_off, `off512` MfccTables::pow_off_512.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
