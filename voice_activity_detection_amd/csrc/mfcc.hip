@@ -55,7 +55,7 @@ constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twi
 constexpr int kRingRows = 3 * kFramesPerWave;                // MFCC rows a wave keeps for the delta stencil
 constexpr int kRingBytes = kRingRows * kNCep * 4;
 constexpr int kDctBytes = kDctSteps * 64 * 8;                // block-shared B operands of the DCT matrix product
-constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes + kPowOffBytes;
+constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes;
 constexpr int kWavesPerSimd = 3;                             // register budget 168; three 52 KB blocks per CU
 constexpr int kDeltaReach = 2;                               // delta(feat, 2) looks two rows to either side
 constexpr int kMaxRunFrames = 256;                           // frames one wave computes for one run, halo rows included
@@ -110,8 +110,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
     float* ring = reinterpret_cast<float*>(wbase + kWaveLdsBytes);           // [kRingRows][12]
     const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
     const double* dctb = reinterpret_cast<const double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
-    const u32x4* pow_off =
-        reinterpret_cast<const u32x4*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes);
     const int off512 = tab->pow_off_512;
 
     LaneConst K;
@@ -124,9 +122,6 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
         const double* dsrc = &tab->dctb[0][0];
         double* ddst = reinterpret_cast<double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
         for (int i = threadIdx.x; i < kDctSteps * 64; i += kThreads) ddst[i] = dsrc[i];
-        const float4* osrc = reinterpret_cast<const float4*>(&tab->pow_off[0][0][0]);
-        float4* odst = reinterpret_cast<float4*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes);
-        for (int i = threadIdx.x; i < kPowOffBytes / 16; i += kThreads) odst[i] = osrc[i];
         __syncthreads();
     }
 
@@ -176,7 +171,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
                 RawFrame raw;
                 frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
                 if (it > 0) filter_sums(parts, en + (it - 1) * 32, K);      // the previous frame's, under this load
-                frame_energies(raw, tws, pow_off, off512, K, ex, parts);
+                frame_energies(raw, tws, off512, K, ex, parts);
             }
             filter_sums(parts, en + (nfr - 1) * 32, K);
             wave_lds_fence();

@@ -139,12 +139,12 @@ static_assert(kPartOffset + kPartBytes <= kExBytes, "the power spectrum and the 
 // Block-shared LDS image of the W1024 twiddles tw1[15][64] (the head of MfccTables); the other two sets
 // live in registers.
 constexpr int kTwFloat2s = 15 * 64;
-constexpr int kPowOffBytes = 2 * 64 * 8 * 2;   // block-shared LDS image of MfccTables::pow_off
 
 // Loop-invariant per-lane constants that stay in registers (the twiddles do not: see frame_energies).
 struct LaneConst {
     float2 tw2[15];                           // s_a W64^(a q) of this lane's a  } the twiddle sets that fit the
     float2 twr[8];                            // W2048^fft_bin(lane, u)          } registers at 3 waves per SIMD
+    unsigned pow_lo[8], pow_hi[8];            // byte offsets of the lane's bins in the power-spectrum image
     int run_count;
     float run_inv, run_w0, run_f0;
     int rise_first, rise_n, fall_first, fall_n;
@@ -155,6 +155,11 @@ __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* 
     for (int k = 0; k < 15; ++k) K.tw2[k] = tab->tw2[k][lane & 3];
 #pragma unroll
     for (int j = 0; j < 8; ++j) K.twr[j] = tab->twr[j][lane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        K.pow_lo[j] = tab->pow_off[0][lane][j];
+        K.pow_hi[j] = tab->pow_off[1][lane][j];
+    }
     const int run_start = tab->run_start[lane];
     K.run_count = tab->run_count[lane];
     const float b0 = (float)tab->run_b0[lane], b1 = (float)tab->run_b1[lane];
@@ -196,12 +201,12 @@ __device__ __forceinline__ void frame_load(RawFrame& raw, const int* __restrict_
 // The W1024 twiddle factors are read from `tws`, a block-shared LDS image of the table, where they are used
 // instead of living in 30 registers: three waves per SIMD need the register file, and reading them from
 // global memory instead makes the kernel texture-path-bound (measured 2.2x slower).
-// `pow_off` is the block's LDS copy of MfccTables::pow_off, `off512` MfccTables::pow_off_512.
+// `off512` is MfccTables::pow_off_512.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, const u32x4* pow_off, int off512,
-                                               const LaneConst& K, float2* ex, float* parts) {
+__device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, int off512, const LaneConst& K,
+                                               float2* ex, float* parts) {
     const int lane = fresh_lane();
     const int k1l = lane >> 2, al = lane & 3;
     float* pw = reinterpret_cast<float*>(ex);                               // aliases ex once the exchange is read
@@ -295,7 +300,6 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     const int plane = zl ? 3 - al : 4 * (16 - k1l) + 3 - al;
     const int plane0 = zl ? (((al + 1) & 2) ? al + 1 : 0) : plane;            // step 0 of lanes 0..3: 0, 2, 3, 0
     const int paddr = plane * 4, paddr0 = plane0 * 4;
-    const u32x4 off_lo = pow_off[lane], off_hi = pow_off[64 + lane];       // 8 + 8 packed 16-bit byte offsets
     unsigned char* pwb = reinterpret_cast<unsigned char*>(pw);
     // all sixteen cross-lane reads are issued ahead of their use: their latency is paid once
     float2 partner[8];
@@ -325,8 +329,7 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         const float2 t = cmul(K.twr[jj], o);
         const float ar = e.x + t.y, ai = e.y - t.x;                       // E - iT
         const float br = e.x - t.y, bi = e.y + t.x;                       // E + iT
-        const unsigned wl = off_lo[jj >> 1], wh = off_hi[jj >> 1];
-        const unsigned o_lo = (jj & 1) ? wl >> 16 : wl & 0xFFFFu, o_hi = (jj & 1) ? wh >> 16 : wh & 0xFFFFu;
+        const unsigned o_lo = K.pow_lo[jj], o_hi = K.pow_hi[jj];
         *reinterpret_cast<float*>(pwb + o_lo) = ar * ar + ai * ai;                            // bin k (x 2^13)
         *reinterpret_cast<float*>(pwb + o_hi) = br * br + bi * bi;                            // bin 1024 - k
     }
