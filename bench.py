@@ -177,9 +177,9 @@ def make_models(kind):
 
 def cpu_baseline(kind, budget_s=14.0):
     """The CPU oracle (float64 numpy/scipy MFCC + torch CPU model, batch 2048) on a bounded sample of the same
-    workload, twice: single-threaded and with the box's CPU share as torch/BLAS threads.  The path is a chain of
-    small operations (166-frame FFT batches, 30 GRU steps of (2048,30)x(30,90) products), so extra threads mostly
-    add synchronisation; `value` is the faster leg and both are reported."""
+    workload, once per thread count in {1, 4, 8, 16} (capped by the box's CPU share).  torch's intra-op threads
+    and the BLAS / OpenMP pools are limited TOGETHER for each leg, so a leg never runs more threads than it is
+    labelled with.  `value` is the fastest leg, `cores` its thread count; every leg is reported."""
     import torch
     from oracle import pipeline_ref, synth_ref
     try:
@@ -205,21 +205,20 @@ def cpu_baseline(kind, budget_s=14.0):
 
     before = torch.get_num_threads()
     share = max(1, min(int(os.environ.get('OMP_NUM_THREADS', '0') or 0) or before, os.cpu_count() or 1))
+    counts = sorted({t for t in (1, 4, 8, 16) if t <= share} | {1})
     legs = {}
-    for threads in sorted({1, share}):
+    for threads in counts:
         torch.set_num_threads(threads)
         with threadpool_limits(limits=threads):
-            reps, dt = leg(budget_s / 2)
+            reps, dt = leg(budget_s / len(counts))
         legs[threads] = {'value': reps * 2000 / FRAMES_PER_HOUR / dt, 'reps': reps, 'seconds': dt}
     torch.set_num_threads(before)
     best = max(legs, key=lambda k: legs[k]['value'])
     return {'value': legs[best]['value'], 'unit': 'audio-hours/s', 'cores': best, 'kind': 'port',
             'by_threads': {str(k): v['value'] for k, v in legs.items()},
-            'sample': '%d x 1 min synthetic audio (2000 frames, 1971 windows each), float64 numpy/scipy MFCC+delta '
-                      'in 166-frame slices + torch CPU %s, batch 2048; %s; host has %d CPUs'
-                      % (legs[best]['reps'], kind,
-                         ', '.join('%d thread(s): %d reps in %.1f s' % (k, v['reps'], v['seconds'])
-                                   for k, v in legs.items()), os.cpu_count())}
+            'legs': {str(k): v for k, v in legs.items()}, 'host_cpus': os.cpu_count(),
+            'sample': '%d x 1 min synthetic audio, f64 numpy MFCC + torch CPU %s batch 2048; best of %s threads: %d'
+                      % (legs[best]['reps'], kind, '/'.join(str(k) for k in counts), best)}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -265,6 +264,90 @@ def pmc_per_unit(prof, kernel_name):
     return None
 
 
+
+# ---------------------------------------------------------------------------------------------
+# the line the driver parses: short (the driver keeps a few KB of output), the full record goes to a file
+
+def _r(x, digits=5):
+    """Floats to `digits` significant digits (the compact line only; the detail file keeps everything)."""
+    if isinstance(x, float):
+        return float('%.*g' % (digits, x))
+    return x
+
+
+def compact_record(out):
+    """The one JSON object printed on stdout, from the full record: contract keys, ONE roofline object, the
+    front end's three yardsticks, one figure per extra configuration and matrix mode, the CPU baseline.
+    No notes, no per-kernel duplicates; every string stays short."""
+    def roof(k):
+        keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes', 'ms_per_launch')
+        return {key: _r(k.get(key)) for key in keep}
+
+    c = {key: _r(out[key]) for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+                                       'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'dtype_note', 'matrix_mode',
+                                       'data', 'dist_backend')}
+    modes = out.get('matrix_modes') or {}
+    if 'f32' in modes:                                  # the strict float32 (fp32 MFMA) figure beside the headline
+        c['value_f32_mfma'] = _r(modes['f32']['value'])
+        c['ms_per_step_f32_mfma'] = _r(modes['f32']['ms_per_step'])
+    c['config'] = out['config']
+    c['x_realtime_per_gpu'] = _r(out['x_realtime_per_gpu'])
+    c['roofline'] = roof(out['roofline'])
+    m, fe = out['kernels']['model'], out['kernels']['frontend']
+    c['model'] = {'kernel': m['kernel'], 'ms': _r(m['ms_per_launch']), 'achieved': _r(m['achieved']),
+                  'peak': _r(m['peak']), 'unit': m['unit'], 'frac': _r(m['frac']),
+                  'frac_of_fp32_peak': _r(m['frac_of_fp32_peak']), 'traffic': _r(m['traffic'])}
+    issue = fe.get('valu_issue') or {}
+    c['frontend'] = {'kernel': fe['kernel'], 'ms': _r(fe['ms_per_launch']), 'GBs': _r(fe['achieved']),
+                     'frac_hbm': _r(fe['frac']), 'frac_fp32': _r(fe['fp32_frac']),
+                     'frac_issue': _r(issue.get('frac')), 'traffic': _r(fe['traffic'])}
+    if out.get('configs'):
+        c['configs'] = {name: {'value': _r(rec['value']), 'ms_per_step': _r(rec['ms_per_step']),
+                               'model_ms': _r(rec['kernels']['model']['ms_per_launch']),
+                               'frac': _r(rec['kernels']['model']['frac'])}
+                        for name, rec in out['configs'].items()}
+    if modes:
+        c['matrix_modes'] = {mm: {'value': _r(v['value']), 'model_ms': _r(v['model_kernel_ms']),
+                                  'max_diff_vs_f32': _r(v['max_abs_posterior_diff_vs_f32'], 3)}
+                             for mm, v in modes.items()}
+    if out.get('cpu_baseline'):
+        b = out['cpu_baseline']
+        c['cpu_baseline'] = {'value': _r(b['value']), 'unit': b['unit'], 'cores': b['cores'], 'kind': b['kind'],
+                             'by_threads': {k: _r(v) for k, v in b['by_threads'].items()}, 'sample': b['sample']}
+    if out.get('detail'):
+        c['detail'] = out['detail']
+    return c
+
+
+COMPACT_LIMIT = 3000      # characters; the driver keeps only a few KB of a run's output
+
+
+def compact_line(out):
+    """compact_record as one JSON line under COMPACT_LIMIT characters: optional parts are dropped, least
+    important first, rather than letting the line outgrow what the driver reads."""
+    c = compact_record(out)
+    for optional in (None, 'matrix_modes', 'configs', 'model', 'frontend'):
+        if optional:
+            c.pop(optional, None)
+        line = json.dumps(c)
+        if len(line) < COMPACT_LIMIT:
+            return line
+    raise ValueError('compact bench record is %d characters' % len(line))
+
+
+def write_detail(out):
+    """The full record (per-kernel rooflines with their notes, every configuration) as a file next to the
+    GPU run's other outputs; returns the path relative to the repository, or None if it cannot be written."""
+    rel = os.environ.get('BENCH_DETAIL', os.path.join('gpurun_out', 'bench_detail.json'))
+    path = os.path.join(ROOT, rel)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        return None
+    return rel
+
 # ---------------------------------------------------------------------------------------------
 
 def main():
@@ -292,6 +375,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # BENCH_FORCE_DIST=1: a single rank still creates its process group and goes through every collective of the
+    # multi-rank path (barrier, MAX / SUM / MIN all_reduce, destroy), so that path can be run on a one-GPU box
+    force_dist = os.environ.get('BENCH_FORCE_DIST', '') not in ('', '0')
+    if force_dist and 'MASTER_ADDR' not in os.environ:
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(s.getsockname()[1]), RANK=str(rank),
+                          WORLD_SIZE=str(world), LOCAL_RANK=str(local))
+        s.close()
     args.gpus = world
     # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a GPU when rehearsing the
     # multi-rank path on a one-GPU box (timing is then meaningless, the control flow is not)
@@ -299,7 +391,7 @@ def main():
     local = local % max(torch.cuda.device_count(), 1) if backend == 'gloo' else local
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -446,7 +538,11 @@ def main():
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': head['config'], 'x_realtime_per_gpu': head['x_realtime_per_gpu'],
                'roofline': head['roofline'], 'roofline_choice': head['roofline_choice'], 'kernels': head['kernels'],
-               'matrix_mode': args.matrix_mode}
+               'matrix_mode': args.matrix_mode,
+               'dtype_note': {'f32': 'float32 MFMA (k-ordered FMA chain)'}.get(
+                   args.matrix_mode, 'f32 operands split exactly into 3 bf16, %s of 9 partial products on the bf16 '
+                                     'MFMA, f32 accumulation' % args.matrix_mode[-1]),
+               'dist_backend': (backend if dist else None)}
 
     if not args.no_configs and args.model == 'gru_large' and args.matrix_mode == 'bf16x8':
         # The other configurations of the measurement plan, 3 steps each on the buffers of the headline run:
@@ -509,7 +605,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu:
             out['cpu_baseline'] = cpu_baseline(args.model)
-        print(json.dumps(out), flush=True)
+        out['detail'] = write_detail(out)
+        print(compact_line(out), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -76,9 +76,10 @@ def all_gather_posteriors(p_local, world, dist=None):
     """Collective gather that leaves the result where the inputs are (device-resident with the NCCL = RCCL
     backend over xGMI, host tensors with gloo): every rank ends up with the posteriors of all windows.
     Shards differ in length by less than two slices, so the ranks exchange their lengths, pad to the
-    longest and trim after one ``all_gather_into_tensor`` (9 bytes per window; 10 MB per 100 h and rank)."""
+    longest and trim after one ``all_gather_into_tensor`` (9 bytes per window; 10 MB per 100 h and rank).
+    With a process group the collectives run for any world size, a single rank included."""
     import torch
-    if dist is None or world == 1:
+    if dist is None:
         return p_local
     n = torch.tensor([p_local.shape[0]], dtype=torch.int64, device=p_local.device)
     counts = torch.empty(world, dtype=torch.int64, device=p_local.device)
