@@ -104,7 +104,10 @@ int vad_mfcc_delta_f32(const int16_t* frames_dev, int64_t n_slices, int64_t fram
  *                    recording, :143), then the n_frames data rows; slice s covers rows
  *                    slice_starts[s] .. slice_starts[s+1] - 1 and its alignment rows are the 3 rows before.
  * slice_starts_dev   n_slices + 1 ascending int64 on the device, [0] = 0, [n_slices] = n_frames;
- *                    empty slices are allowed.
+ *                    empty slices are allowed.  The table is device memory and is NOT validated: entries are
+ *                    clamped into 0 .. n_frames (and a slice to 2^30 frames), so a table that is not ascending or
+ *                    does not end at n_frames leaves output rows unwritten or cut differently, but cannot make
+ *                    the kernel touch memory outside the buffers described here.
  * max_slice_frames   an upper bound of the slice lengths (sizes the launch: one wave per slice up to 256
  *                    frames).  A longer slice is still computed in full, only less evenly spread.
  * Outputs and per-slice semantics as vad_mfcc_delta_f32: output row g = frame g of the stream.
@@ -201,7 +204,7 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
 /*
  * How the stride-1 (window_stride == 24) GRU / LSTM kernels with hidden <= 32, and the wider GRUs' stride-1
  * workspace path (vad_gru_forward_ws_f32), form the float32 products of the recurrence and of the 26-row head.
- * Process-wide; no counterpart in the reference.
+ * Process-wide default (vad_set_matrix_mode) or per call (vad_*_forward_mode_f32); no counterpart in the reference.
  *   VAD_MATRIX_BF16X9  every float32 operand is split exactly into three bfloat16 (x = hi + mid + lo)
  *                      and all nine partial products, each exact in float32, are accumulated in float32 on the
  *                      bf16 matrix pipe (v_mfma_f32_16x16x32_bf16): no operand or product is rounded, only the
@@ -224,8 +227,26 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
 #define VAD_MATRIX_BF16X6 1
 #define VAD_MATRIX_BF16X9 2
 #define VAD_MATRIX_BF16X8 3
+#define VAD_MATRIX_DEFAULT (-1)   /* per-call argument only: use the process-wide mode */
 int vad_set_matrix_mode(int mode);
 int vad_get_matrix_mode(void);
+
+/*
+ * vad_gru_forward_ws_f32 / vad_lstm_forward_f32 with the matrix mode as an argument of the call instead of the
+ * process-wide setting, so that models (or callers, or streams) of one process can differ in it: one model
+ * bit-identical to its dense-batch forward() (VAD_MATRIX_F32), another on the faster split products.
+ * matrix_mode is one of the VAD_MATRIX_* values above; VAD_MATRIX_DEFAULT reads the process-wide mode
+ * at the time of the call.  The GRU form takes the optional workspace of vad_gru_forward_ws_f32
+ * (NULL / 0 = none).  Same Net.forward semantics (core/models.py:39-81) as the calls they extend.
+ */
+int vad_gru_forward_mode_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                             const float* blob_dev, int hidden, int large,
+                             float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold,
+                             int matrix_mode, void* workspace_dev, size_t workspace_bytes, void* stream);
+int vad_lstm_forward_mode_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                              const float* blob_dev, int hidden, int large,
+                              float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold,
+                              int matrix_mode, void* stream);
 
 /*
  * Sampled windows: window w starts at feature row window_rows_dev[w] of a packed

@@ -105,6 +105,11 @@ def test_argument_checks_reject_before_any_device_work(L):
         ('vad_gru_forward_f32', (ok, 1, 722, ok, 30, 1, ok, None, 0, f0, None), b'window_stride'),
         ('vad_gru_forward_f32', (odd, 1, 720, ok, 30, 1, ok, None, 0, f0, None), b'16-byte aligned'),
         ('vad_gru_forward_f32', (ok, 1, 720, ok, 30, 1, ok, None, 7, f0, None), b'decision_mode'),
+        ('vad_gru_forward_mode_f32', (ok, 1, 24, ok, 30, 1, ok, None, 0, f0, 4, None, 0, None), b'matrix mode'),
+        ('vad_gru_forward_mode_f32', (ok, 1, 24, ok, 30, 1, ok, None, 0, f0, -2, None, 0, None), b'matrix mode'),
+        ('vad_gru_forward_mode_f32', (ok, 1, 24, ok, 90, 1, ok, None, 0, f0, 0, None, 64, None), b'null workspace'),
+        ('vad_lstm_forward_mode_f32', (ok, 1, 24, ok, 30, 1, ok, None, 0, f0, 17, None), b'matrix mode'),
+        ('vad_lstm_forward_mode_f32', (ok, 1, 24, ok, 33, 1, ok, None, 0, f0, -1, None), b'hidden'),
         ('vad_densenet_forward_f32', (ok, 1, 720, None, 0, ok, None, 0, f0, None), b'null pointer'),
         ('vad_densenet_forward_f32', (ok, 1, 721, ok, 0, ok, None, 0, f0, None), b'window_stride'),
         ('vad_gru_forward_rows_f32', (ok, 29, ok, 1, ok, 30, 1, ok, None, 0, f0, None), b'at least 30 rows'),

@@ -404,11 +404,11 @@ def test_wide_gru_split_kernel(vad, hidden, large, mode):
         cap = type(net).WORKSPACE_CAP
         try:
             type(net).WORKSPACE_CAP = 100 * 3 * ((hidden + 31) // 32) * 32 * 4       # 100 rows: 71 windows per chunk
-            net._ws = None
+            net._ws.clear()
             p_chunks, _ = net.score(feat, window_stride=24)
         finally:
             type(net).WORKSPACE_CAP = cap
-            net._ws = None
+            net._ws.clear()
         p_whole, _ = net.score(feat, window_stride=24)
         assert torch.equal(p_chunks, p_whole)
     finally:
@@ -487,3 +487,111 @@ def test_sampled_windows_wide_gru(vad, hidden):
     with torch.no_grad():
         y = ref(batch.cpu()).numpy()
     assert np.abs(p.cpu().numpy() - y).max() <= ATOL
+
+
+def test_wide_gru_scratch_is_per_stream(vad):
+    """A GRU with more than 32 units projects its feature rows into scratch memory before the steps read them.
+    The module keeps one scratch buffer per (device, stream), so the same net scoring different inputs on two
+    streams at once gives the results of one-at-a-time runs, in the float32 and in the split mode; a caller's
+    own workspace tensor does the same."""
+    ref = models_ref.make_model('gru_large', hidden=90)
+    net = vad.Net(large=True, lstm=False, hidden=90)
+    net.load_state_dict(ref.state_dict())
+    n = 30000
+    rng = np.random.default_rng(11)
+    fa = torch.tensor(rng.normal(0, 8, size=(n, 24)).astype(np.float32)).cuda()
+    fb = torch.tensor(rng.normal(0, 8, size=(n, 24)).astype(np.float32)).cuda()
+    for mm in ('f32', 'bf16x8'):
+        pa, _ = net.score(fa, window_stride=24, matrix_mode=mm)
+        pb, _ = net.score(fb, window_stride=24, matrix_mode=mm)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = {}
+        for _ in range(4):
+            with torch.cuda.stream(s1):
+                outs['a'] = net.score(fa, window_stride=24, matrix_mode=mm)[0]
+            with torch.cuda.stream(s2):
+                outs['b'] = net.score(fb, window_stride=24, matrix_mode=mm)[0]
+        s1.synchronize()
+        s2.synchronize()
+        assert torch.equal(outs['a'], pa) and torch.equal(outs['b'], pb), mm
+        own = torch.empty(net.workspace_bytes(n - 29), dtype=torch.uint8, device='cuda')
+        assert torch.equal(net.score(fa, window_stride=24, matrix_mode=mm, workspace=own)[0], pa)
+    assert len(net._ws) >= 3                           # default stream + the two side streams
+    with pytest.raises(ValueError):
+        net.score(fa, window_stride=24, workspace=torch.empty(64, dtype=torch.float32, device='cuda'))
+
+
+def test_wide_gru_is_capturable_after_reserving_its_scratch(vad):
+    """reserve_workspace() moves the wide GRU's one allocation out of a graph capture."""
+    ref = models_ref.make_model('gru_large', hidden=90)
+    net = vad.Net(large=True, lstm=False, hidden=90)
+    net.load_state_dict(ref.state_dict())
+    n = 5000
+    rng = np.random.default_rng(12)
+    feat = torch.tensor(rng.normal(0, 8, size=(n, 24)).astype(np.float32)).cuda()
+    p_direct, d_direct = net.score(feat, window_stride=24)
+    p = torch.empty_like(p_direct)
+    d = torch.empty_like(d_direct)
+    vad.init()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ws = torch.empty(net.workspace_bytes(n - 29), dtype=torch.uint8, device='cuda')
+    with torch.cuda.graph(g, stream=side):
+        net.score(feat, window_stride=24, out=p, decisions=d, workspace=ws)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(p, p_direct) and torch.equal(d, d_direct)
+    assert net.reserve_workspace(n - 29).numel() >= net.workspace_bytes(n - 29)
+
+
+def test_matrix_mode_is_a_property_of_the_call(vad):
+    """Two Nets of one process score the same features in different matrix modes at the same time on two streams
+    and each gets what a run in its own mode alone gives; the process-wide mode is only the default."""
+    ref = models_ref.make_model('gru_large')
+    n = 40000
+    rng = np.random.default_rng(13)
+    feat = torch.tensor(rng.normal(0, 8, size=(n, 24)).astype(np.float32)).cuda()
+    expected = {}
+    for mm in ('f32', 'bf16x8'):
+        prev = vad.set_matrix_mode(mm)
+        plain = vad.Net(large=True, lstm=False)
+        plain.load_state_dict(ref.state_dict())
+        expected[mm] = plain.score(feat, window_stride=24)[0].clone()
+        vad.set_matrix_mode(prev)
+    assert not torch.equal(expected['f32'], expected['bf16x8'])
+    assert float((expected['f32'] - expected['bf16x8']).abs().max()) <= 1e-5
+    strict = vad.Net(large=True, lstm=False, matrix_mode='f32')
+    fast = vad.Net(large=True, lstm=False, matrix_mode='bf16x8')
+    strict.load_state_dict(ref.state_dict())
+    fast.load_state_dict(ref.state_dict())
+    strict.score(feat[:64], window_stride=24)              # pack the weights outside the overlapped part
+    fast.score(feat[:64], window_stride=24)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for globally in ('bf16x6', 'f32'):                         # whatever the process-wide mode says
+        prev = vad.set_matrix_mode(globally)
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                ps = strict.score(feat, window_stride=24)[0]
+            with torch.cuda.stream(s2):
+                pf = fast.score(feat, window_stride=24)[0]
+        s1.synchronize()
+        s2.synchronize()
+        vad.set_matrix_mode(prev)
+        assert torch.equal(ps, expected['f32']) and torch.equal(pf, expected['bf16x8'])
+    # strict float32 stride-1 windows are the bits of the dense-batch forward()
+    idx = torch.arange(0, 2048, device='cuda')[:, None] + torch.arange(30, device='cuda')[None, :]
+    assert torch.equal(strict(feat[idx]), expected['f32'][:2048])
+    # per call beats per model; LSTM takes the argument too
+    assert torch.equal(strict.score(feat, window_stride=24, matrix_mode='bf16x8')[0], expected['bf16x8'])
+    lref = models_ref.make_model('lstm_small')
+    lstm = vad.Net(large=False, lstm=True)
+    lstm.load_state_dict(lref.state_dict())
+    a = lstm.score(feat, window_stride=24, matrix_mode='f32')[0]
+    b = lstm.score(feat, window_stride=24, matrix_mode='bf16x9')[0]
+    assert not torch.equal(a, b) and float((a - b).abs().max()) <= 1e-5
+    with pytest.raises(ValueError):
+        lstm.score(feat, window_stride=24, matrix_mode='fp8')

@@ -25,7 +25,7 @@ SYMBOLS = [
     'vad_densenet_blob_floats', 'vad_densenet_tensor_count', 'vad_pack_densenet_weights',
     'vad_gru_forward_f32', 'vad_lstm_forward_f32', 'vad_densenet_forward_f32', 'vad_gru_forward_ws_f32', 'vad_gru_workspace_bytes',
     'vad_synth_audio_i16', 'vad_overlay_i16', 'vad_threshold_sweep_f32', 'vad_threshold_sweep_noalloc_f32',
-    'vad_set_matrix_mode', 'vad_get_matrix_mode', 'vad_gru_forward_rows_f32', 'vad_lstm_forward_rows_f32', 'vad_densenet_forward_rows_f32',
+    'vad_set_matrix_mode', 'vad_get_matrix_mode', 'vad_gru_forward_mode_f32', 'vad_lstm_forward_mode_f32', 'vad_gru_forward_rows_f32', 'vad_lstm_forward_rows_f32', 'vad_densenet_forward_rows_f32',
 ]
 
 
@@ -98,6 +98,10 @@ def lib():
     L.vad_lstm_forward_f32.argtypes = fwd
     L.vad_gru_forward_ws_f32.restype = ctypes.c_int
     L.vad_gru_forward_ws_f32.argtypes = fwd[:-1] + [c_void, ctypes.c_size_t, c_void]
+    L.vad_gru_forward_mode_f32.restype = ctypes.c_int
+    L.vad_gru_forward_mode_f32.argtypes = fwd[:-1] + [ctypes.c_int, c_void, ctypes.c_size_t, c_void]
+    L.vad_lstm_forward_mode_f32.restype = ctypes.c_int
+    L.vad_lstm_forward_mode_f32.argtypes = fwd[:-1] + [ctypes.c_int, c_void]
     L.vad_gru_workspace_bytes.restype = ctypes.c_size_t
     L.vad_gru_workspace_bytes.argtypes = [ctypes.c_int, c_i64]
     L.vad_densenet_forward_f32.restype = ctypes.c_int

@@ -131,12 +131,19 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
     const long s = run / m.runs_per_slice;
     const int part = (int)(run - s * m.runs_per_slice);
     long g_lo;
-    int n;                                                   // frames of the slice (< 2^31, checked by the host)
+    int n;                                                   // frames of the slice
     const int16_t* rows;
     if (m.starts) {
         // the table is read through vector loads: tell the compiler the values are wave-uniform, or every loop
         // variable derived from them occupies a vector register
-        const long lo = (long)m.starts[s], hi = (long)m.starts[s + 1];
+        // The table is the caller's and is not validated on the host (it lives on the device): both ends are
+        // clamped into 0 .. n_frames and a slice is cut at 2^30 frames, so that a bad table can leave rows
+        // unwritten or computed with the wrong neighbours but cannot read or write outside the buffers.
+        long hi = (long)m.starts[s + 1];
+        hi = hi < 0 ? 0 : (hi > m.n_frames ? m.n_frames : hi);
+        long lo = (long)m.starts[s];
+        lo = lo < 0 ? 0 : (lo > hi ? hi : lo);
+        if (hi - lo > (1L << 30)) hi = lo + (1L << 30);
         g_lo = ((long)__builtin_amdgcn_readfirstlane((int)(lo >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)(lo & 0xFFFFFFFFL));
         n = __builtin_amdgcn_readfirstlane((int)(hi - lo));

@@ -957,7 +957,7 @@ struct Workspace {
 
 template <bool LARGE, int UT, int KL>
 int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec, int mode,
-                float threshold, Workspace ws, hipStream_t st) {
+                float threshold, Workspace ws, int matrix_mode, hipStream_t st) {
     const NetLayout L = net_layout(false, LARGE, UT);
     int rc = ensure_rnn_attrs();
     if (rc != VAD_OK) return rc;
@@ -971,7 +971,6 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
         const long chunk = ws_rows - (kT - 1);
         const size_t lds_bytes = (size_t)(L.head - L.a_hh) * sizeof(float);
         const size_t split_lds_bytes = (size_t)wide_split_lds_floats(UT) * sizeof(float);
-        const int matrix_mode = g_matrix_mode.load(std::memory_order_relaxed);
         for (long w0 = 0; w0 < n_windows; w0 += chunk) {
             const long nw = n_windows - w0 < chunk ? n_windows - w0 : chunk;
             const long rows = nw + kT - 1;
@@ -1011,11 +1010,11 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
 
 template <bool LARGE, int UT>
 int launch_wide_kl(int hidden, const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec,
-                   int mode, float threshold, Workspace ws, hipStream_t st) {
+                   int mode, float threshold, Workspace ws, int matrix_mode, hipStream_t st) {
     // k-steps of the last tile that carry units; the two instantiations cover hidden 90 (13) and everything else
     return tile_k_steps(tile_units(hidden, UT - 1)) <= 13
-               ? launch_wide<LARGE, UT, 13>(x, n_windows, wm, blob, p, dec, mode, threshold, ws, st)
-               : launch_wide<LARGE, UT, 16>(x, n_windows, wm, blob, p, dec, mode, threshold, ws, st);
+               ? launch_wide<LARGE, UT, 13>(x, n_windows, wm, blob, p, dec, mode, threshold, ws, matrix_mode, st)
+               : launch_wide<LARGE, UT, 16>(x, n_windows, wm, blob, p, dec, mode, threshold, ws, matrix_mode, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1023,8 +1022,7 @@ int launch_wide_kl(int hidden, const float* x, long n_windows, WindowMap wm, con
 
 template <bool LSTM, bool LARGE, int KS>
 int launch_ks(const float* x, long n_windows, WindowMap wm, const float* blob, float* p, uint8_t* dec, int mode,
-           float threshold, hipStream_t st) {
-    const int matrix_mode = g_matrix_mode.load(std::memory_order_relaxed);
+           float threshold, int matrix_mode, hipStream_t st) {
     if (!wm.rows && wm.stride == kF && matrix_mode != VAD_MATRIX_F32) {
         using C = SplitCfg<LSTM>;
         int rc = ensure_rnn_attrs();
@@ -1069,17 +1067,21 @@ int launch_ks(const float* x, long n_windows, WindowMap wm, const float* blob, f
 
 template <bool LSTM, bool LARGE>
 int launch(const float* x, long n_windows, WindowMap wm, const float* blob, int hidden, float* p, uint8_t* dec, int mode,
-           float threshold, hipStream_t st) {
+           float threshold, int matrix_mode, hipStream_t st) {
     return hidden_k_steps(hidden) <= kHk - 1
-               ? launch_ks<LSTM, LARGE, kHk - 1>(x, n_windows, wm, blob, p, dec, mode, threshold, st)
-               : launch_ks<LSTM, LARGE, kHk>(x, n_windows, wm, blob, p, dec, mode, threshold, st);
+               ? launch_ks<LSTM, LARGE, kHk - 1>(x, n_windows, wm, blob, p, dec, mode, threshold, matrix_mode, st)
+               : launch_ks<LSTM, LARGE, kHk>(x, n_windows, wm, blob, p, dec, mode, threshold, matrix_mode, st);
 }
 
 }  // namespace
 
+static bool valid_matrix_mode(int m) {
+    return m == VAD_MATRIX_F32 || m == VAD_MATRIX_BF16X6 || m == VAD_MATRIX_BF16X9 || m == VAD_MATRIX_BF16X8;
+}
+
 int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, const float* blob, int hidden, int large,
-                float* p, uint8_t* dec, int mode, float threshold, void* stream, float* ws_ptr = nullptr,
-                size_t ws_bytes = 0) {
+                float* p, uint8_t* dec, int mode, float threshold, void* stream, int matrix_mode = VAD_MATRIX_DEFAULT,
+                float* ws_ptr = nullptr, size_t ws_bytes = 0) {
     const long wstride = wm.stride;
     VAD_REQUIRE(x && blob && p, "null pointer argument");
     VAD_REQUIRE(hidden >= 1 && hidden <= (lstm ? kHp : 3 * kHp),
@@ -1090,29 +1092,29 @@ int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, cons
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(blob) & 15) == 0, "blob_dev must be 16-byte aligned");
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(p) & 7) == 0, "p_dev must be 8-byte aligned");
     VAD_REQUIRE(mode == VAD_DECIDE_ARGMAX || mode == VAD_DECIDE_THRESHOLD, "unknown decision_mode %d", mode);
+    VAD_REQUIRE(matrix_mode == VAD_MATRIX_DEFAULT || valid_matrix_mode(matrix_mode), "unknown matrix mode %d", matrix_mode);
+    if (matrix_mode == VAD_MATRIX_DEFAULT) matrix_mode = g_matrix_mode.load(std::memory_order_relaxed);
     if (n_windows == 0) return VAD_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (lstm) {
-        return large ? launch<true, true>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st)
-                     : launch<true, false>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st);
+        return large ? launch<true, true>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, matrix_mode, st)
+                     : launch<true, false>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, matrix_mode, st);
     }
     const Workspace ws{ws_ptr, ws_bytes};
     if (hidden > 2 * kHp)
-        return large ? launch_wide_kl<true, 3>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, st)
-                     : launch_wide_kl<false, 3>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, st);
+        return large ? launch_wide_kl<true, 3>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, matrix_mode, st)
+                     : launch_wide_kl<false, 3>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, matrix_mode, st);
     if (hidden > kHp)
-        return large ? launch_wide_kl<true, 2>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, st)
-                     : launch_wide_kl<false, 2>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, st);
-    return large ? launch<false, true>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st)
-                 : launch<false, false>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, st);
+        return large ? launch_wide_kl<true, 2>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, matrix_mode, st)
+                     : launch_wide_kl<false, 2>(hidden, x, n_windows, wm, blob, p, dec, mode, threshold, ws, matrix_mode, st);
+    return large ? launch<false, true>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, matrix_mode, st)
+                 : launch<false, false>(x, n_windows, wm, blob, hidden, p, dec, mode, threshold, matrix_mode, st);
 }
 
 }  // namespace vad
 
 extern "C" int vad_set_matrix_mode(int mode) {
-    VAD_REQUIRE(mode == VAD_MATRIX_F32 || mode == VAD_MATRIX_BF16X6 || mode == VAD_MATRIX_BF16X9 ||
-                    mode == VAD_MATRIX_BF16X8,
-                "unknown matrix mode %d", mode);
+    VAD_REQUIRE(vad::valid_matrix_mode(mode), "unknown matrix mode %d", mode);
     vad::g_matrix_mode.store(mode, std::memory_order_relaxed);
     return VAD_OK;
 }
@@ -1312,7 +1314,27 @@ extern "C" int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int
     VAD_REQUIRE(workspace_dev || workspace_bytes == 0, "null workspace with a non-zero size");
     VAD_REQUIRE((reinterpret_cast<uintptr_t>(workspace_dev) & 15) == 0, "workspace_dev must be 16-byte aligned");
     return rnn_forward(false, x_dev, n_windows, WindowMap{(long)window_stride, nullptr, 0}, blob_dev, hidden, large, p_dev,
-                       decision_dev, decision_mode, threshold, stream, static_cast<float*>(workspace_dev), workspace_bytes);
+                       decision_dev, decision_mode, threshold, stream, VAD_MATRIX_DEFAULT, static_cast<float*>(workspace_dev),
+                       workspace_bytes);
+}
+
+extern "C" int vad_gru_forward_mode_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,
+                                        int hidden, int large, float* p_dev, uint8_t* decision_dev, int decision_mode,
+                                        float threshold, int matrix_mode, void* workspace_dev, size_t workspace_bytes,
+                                        void* stream) {
+    using namespace vad;
+    VAD_REQUIRE(workspace_dev || workspace_bytes == 0, "null workspace with a non-zero size");
+    VAD_REQUIRE((reinterpret_cast<uintptr_t>(workspace_dev) & 15) == 0, "workspace_dev must be 16-byte aligned");
+    return rnn_forward(false, x_dev, n_windows, WindowMap{(long)window_stride, nullptr, 0}, blob_dev, hidden, large, p_dev,
+                       decision_dev, decision_mode, threshold, stream, matrix_mode, static_cast<float*>(workspace_dev),
+                       workspace_bytes);
+}
+
+extern "C" int vad_lstm_forward_mode_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,
+                                         int hidden, int large, float* p_dev, uint8_t* decision_dev, int decision_mode,
+                                         float threshold, int matrix_mode, void* stream) {
+    return vad::rnn_forward(true, x_dev, n_windows, vad::WindowMap{(long)window_stride, nullptr, 0}, blob_dev, hidden,
+                            large, p_dev, decision_dev, decision_mode, threshold, stream, matrix_mode);
 }
 
 extern "C" int vad_lstm_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride, const float* blob_dev,

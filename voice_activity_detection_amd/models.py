@@ -23,7 +23,8 @@ MATRIX_MODES = {'f32': 0, 'bf16x6': 1, 'bf16x9': 2, 'bf16x8': 3}
 
 
 def set_matrix_mode(mode):
-    """Process-wide: how the stride-1 GRU / LSTM kernels (and the wide GRU's stride-1 workspace path) form their
+    """Process-wide default (a model's ``matrix_mode`` attribute or ``score(matrix_mode=...)`` override it per
+    model / per call): how the stride-1 GRU / LSTM kernels (and the wide GRU's stride-1 workspace path) form their
     float32 matrix products.
     'bf16x9' splits every float32 operand exactly into three bfloat16 and accumulates all nine exact partial
     products in float32 on the bf16 matrix pipe; 'bf16x8' (default) leaves out the lo * lo product, under 2^-30
@@ -59,7 +60,8 @@ class _HipModule(nn.Module):
     def _pack(self):                                   # -> numpy float32 blob
         raise NotImplementedError
 
-    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream, matrix_mode=None,
+                workspace=None):
         raise NotImplementedError
 
     def _weights_on(self, device):
@@ -69,7 +71,8 @@ class _HipModule(nn.Module):
             self._blob_key = key
         return self._blob
 
-    def score(self, x, window_stride=None, n_windows=None, threshold=None, out=None, decisions=None):
+    def score(self, x, window_stride=None, n_windows=None, threshold=None, out=None, decisions=None,
+              matrix_mode=None, workspace=None):
         """Posteriors for many windows without materialising them.
 
         ``x``  float32 CUDA tensor.  A (B,30,24) batch, or -- with
@@ -80,8 +83,17 @@ class _HipModule(nn.Module):
         Returns ``(p (n,2) float32, decision (n,) uint8)``; the decision is the
         argmax (core/train.py:605-607) or ``p[:,1] >= threshold``
         (core/train.py:486-487).
+
+        ``matrix_mode``  'f32', 'bf16x9', 'bf16x8' or 'bf16x6' for this call (GRU / LSTM over stride-1
+               windows; see ``set_matrix_mode``).  None: the module's ``matrix_mode`` attribute, and if
+               that is None too, the process-wide mode.
+        ``workspace``    uint8 CUDA tensor for the stride-1 scratch of GRUs with more than 32 units
+               (``Net.workspace_bytes``); None: a buffer the module keeps per (device, stream).
         """
         L = _lib.lib()
+        matrix_mode = matrix_mode if matrix_mode is not None else getattr(self, 'matrix_mode', None)
+        if matrix_mode is not None and matrix_mode not in MATRIX_MODES:
+            raise ValueError('matrix mode must be one of %s' % sorted(MATRIX_MODES))
         if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous():
             raise ValueError('x must be a contiguous float32 CUDA tensor')
         if window_stride is None:
@@ -106,7 +118,7 @@ class _HipModule(nn.Module):
                                     ctypes.c_void_p(blob.data_ptr()), ctypes.c_void_p(p.data_ptr()),
                                     ctypes.c_void_p(d.data_ptr()), mode,
                                     ctypes.c_float(0.0 if threshold is None else threshold),
-                                    _lib.current_stream()))
+                                    _lib.current_stream(), matrix_mode, workspace))
         return p, d
 
     def score_rows(self, feat, window_rows, threshold=None, out=None, decisions=None):
@@ -151,12 +163,16 @@ class _HipModule(nn.Module):
 class Net(_HipModule):
     """core/models.py:9-81: 1-layer LSTM or GRU (24 -> 30), flatten, lin1+ReLU+lin2 or lin, softmax."""
 
-    def __init__(self, large=True, lstm=True, hidden=FRAMES):
+    def __init__(self, large=True, lstm=True, hidden=FRAMES, matrix_mode=None):
         # ``hidden`` is an extension: the reference hard-wires FRAMES = 30 (core/models.py:19-25); the
-        # enlarged-GRU benchmark configuration uses 90.
+        # enlarged-GRU benchmark configuration uses 90.  ``matrix_mode`` (also an extension) fixes how this
+        # model's stride-1 kernels form their float32 products; None follows the process-wide mode.
         super().__init__()
+        if matrix_mode is not None and matrix_mode not in MATRIX_MODES:
+            raise ValueError('matrix mode must be one of %s' % sorted(MATRIX_MODES))
         self.large = large
         self.lstm = lstm
+        self.matrix_mode = matrix_mode
         self.relu = nn.ReLU()
         cls = nn.LSTM if lstm else nn.GRU
         self.rnn = cls(input_size=FEATURES, hidden_size=hidden, num_layers=1, batch_first=True)
@@ -164,6 +180,7 @@ class Net(_HipModule):
         self.lin2 = nn.Linear(26, 2)
         self.lin = nn.Linear(FRAMES * hidden, 2)
         self.softmax = nn.Softmax(dim=1)
+        self._ws = {}
 
     def _pack(self):
         L = _lib.lib()
@@ -184,20 +201,53 @@ class Net(_HipModule):
     # largest scratch the wide GRU's stride-1 path is given (bigger launches go in chunks)
     WORKSPACE_CAP = 16 << 30
 
-    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+    def workspace_bytes(self, n_windows):
+        """Scratch the stride-1 path of a GRU with more than 32 units uses for ``n_windows`` windows (0 for the
+        other models): the size of the ``workspace`` tensor ``score`` accepts."""
+        if self.lstm or self.rnn.hidden_size <= 32:
+            return 0
+        return min(_lib.lib().vad_gru_workspace_bytes(self.rnn.hidden_size, n_windows), self.WORKSPACE_CAP)
+
+    def reserve_workspace(self, n_windows, device=None):
+        """Allocate the module-kept scratch for the CURRENT stream of ``device`` ahead of time, e.g. before
+        a HIP graph capture (the first ``score`` on a stream allocates it otherwise)."""
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(dev):
+            return self._workspace(self.workspace_bytes(n_windows), dev)
+
+    def _workspace(self, need, dev):
+        # One buffer per (device, stream): launches of this module on different streams must not share
+        # scratch, and a buffer is only ever replaced by the stream that uses it (the allocator reuses the
+        # memory in that stream's order, so work still in flight on it finishes first).
+        if need == 0:
+            return None
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws[key] = ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return ws
+
+    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream, matrix_mode=None,
+                workspace=None):
         H = self.rnn.hidden_size
-        if not self.lstm and H > 32 and stride == FEATURES:
-            # projected feature rows of the wide GRU live in a workspace this module owns (reused across calls)
-            need = min(L.vad_gru_workspace_bytes(H, n), self.WORKSPACE_CAP)
+        mm = -1 if matrix_mode is None else MATRIX_MODES[matrix_mode]          # -1 = VAD_MATRIX_DEFAULT
+        if self.lstm:
+            return L.vad_lstm_forward_mode_f32(x_ptr, n, stride, blob_ptr, H, int(self.large), p_ptr, d_ptr, mode, thr,
+                                               mm, stream)
+        ws_ptr, ws_bytes = None, 0
+        if H > 32 and stride == FEATURES:
+            # projected feature rows of the wide GRU: the caller's workspace, or one this module keeps
             dev = torch.device('cuda', torch.cuda.current_device())
-            ws = getattr(self, '_ws', None)
-            if ws is None or ws.device != dev or ws.numel() < need:
-                self._ws = ws = None                    # release before growing
-                self._ws = ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            return L.vad_gru_forward_ws_f32(x_ptr, n, stride, blob_ptr, H, int(self.large), p_ptr, d_ptr, mode, thr,
-                                            ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream)
-        fn = L.vad_lstm_forward_f32 if self.lstm else L.vad_gru_forward_f32
-        return fn(x_ptr, n, stride, blob_ptr, H, int(self.large), p_ptr, d_ptr, mode, thr, stream)
+            if workspace is not None:
+                if not workspace.is_cuda or workspace.dtype != torch.uint8 or not workspace.is_contiguous() \
+                        or workspace.device != dev:
+                    raise ValueError('workspace must be a contiguous uint8 CUDA tensor on the device of x')
+                ws = workspace
+            else:
+                ws = self._workspace(self.workspace_bytes(n), dev)
+            ws_ptr, ws_bytes = ctypes.c_void_p(ws.data_ptr()), ws.numel()
+        return L.vad_gru_forward_mode_f32(x_ptr, n, stride, blob_ptr, H, int(self.large), p_ptr, d_ptr, mode, thr,
+                                          mm, ws_ptr, ws_bytes, stream)
 
     def _launch_rows(self, L, f_ptr, n_rows, r_ptr, n, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
         fn = L.vad_lstm_forward_rows_f32 if self.lstm else L.vad_gru_forward_rows_f32
@@ -263,7 +313,9 @@ class DenseNet(_HipModule):
         _lib.check(L.vad_pack_densenet_weights(int(self.large), ptrs, len(arrays), _lib.host_ptr(blob), n))
         return blob
 
-    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream, matrix_mode=None,
+                workspace=None):
+        # DenseNet always computes on the float32 MFMA: the matrix mode does not apply
         return L.vad_densenet_forward_f32(x_ptr, n, stride, blob_ptr, int(self.large), p_ptr, d_ptr, mode, thr, stream)
 
     def _launch_rows(self, L, f_ptr, n_rows, r_ptr, n, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
