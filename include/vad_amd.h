@@ -268,6 +268,55 @@ int vad_densenet_forward_rows_f32(const float* feat_dev, int64_t n_rows, const i
                                   float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold, void* stream);
 
 /*
+ * NickNet, the reference's conv + GRU hybrid (core/models.py:245-330), in its default configuration:
+ * gated convolutions (GatedConv, core/models.py:180-202: tanh(BN(conv)) * sigmoid(BN(conv_gate)), kernel 3,
+ * padding 1), no residual connections, uni-directional GRU and the fully connected `embed` head of BiRNN
+ * (core/models.py:84-128), eval mode.  large: channels 24 -> 32 -> 28 -> 25 -> 18, GRU 18 -> 29 -> 29 (2 layers),
+ * embed 58 -> 32 -> 18 -> 2; small: 24 -> 20 -> 18 -> 16, GRU 16 -> 21, embed 21 -> 18 -> 2.
+ *
+ * The reference's NickNet.forward raises between the GRU and `embed` (BiRNN.forward flattens all 30 GRU outputs
+ * into 870 columns where `embed` takes L*H = 58 / 21, core/models.py:166-174), so the whole-model output has no
+ * reference counterpart.  The conv trunk (core/models.py:308-323), the GRU (:151,162) and `embed` (:109-128)
+ * do run in the reference and are what vad_nicknet_stages_f32 / vad_nicknet_embed_f32 expose for checking.
+ * The head input used here is the final hidden state of every GRU layer, h_n.permute(1,0,2).reshape(B, L*H).
+ *
+ * `tensors_host`: the float tensors of the module in state_dict() order, skipping num_batches_tracked:
+ * per conv layer conv.0.weight (cout,cin,3), conv.0.bias, conv.1.{weight,bias,running_mean,running_var} and
+ * the same six of conv_gate; per GRU layer weight_ih, weight_hh, bias_ih, bias_hh; per hidden embed stage
+ * Linear weight, bias and BatchNorm1d weight, bias, running_mean, running_var; the last Linear's weight, bias.
+ * 70 tensors (large) or 48 (small).  BatchNorm uses eps = 1e-5 and is folded into the weights.
+ */
+size_t vad_nicknet_blob_floats(int large);
+int vad_nicknet_tensor_count(int large);
+int vad_pack_nicknet_weights(int large, const float* const* tensors_host, int n_tensors,
+                             float* blob_host, size_t blob_floats);
+/* Windows -> posteriors and decisions; arguments as vad_densenet_forward_f32 / vad_densenet_forward_rows_f32. */
+int vad_nicknet_forward_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                            const float* blob_dev, int large,
+                            float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold,
+                            void* stream);
+int vad_nicknet_forward_rows_f32(const float* feat_dev, int64_t n_rows, const int64_t* window_rows_dev,
+                                 int64_t n_windows, const float* blob_dev, int large,
+                                 float* p_dev, uint8_t* decision_dev, int decision_mode, float threshold, void* stream);
+/*
+ * The same forward with the outputs of its sub-modules written out in the reference's layouts (any may be NULL):
+ *   trunk_out_dev   (B, C, 30)  conv1 .. conv4 of x.permute(0,2,1)                 core/models.py:308-323
+ *   seq_out_dev     (B, 30, H)  outputs of the last GRU layer, net.rnn.rnn(...)[0]   core/models.py:162
+ *   hn_out_dev      (L, B, H)   final hidden state of every GRU layer, net.rnn.rnn(...)[1]
+ *   logits_out_dev  (B, 2)      embed output before the softmax                      core/models.py:177
+ *   p_dev           (B, 2)      softmax                                              core/models.py:330
+ * Exactly one of x_dev (windows, as above) and trunk_in_dev (a (B, C, 30) trunk output to start the GRU
+ * from, e.g. the reference's own) is given.
+ */
+int vad_nicknet_stages_f32(const float* x_dev, int64_t n_windows, int64_t window_stride,
+                           const float* trunk_in_dev, const float* blob_dev, int large,
+                           float* trunk_out_dev, float* seq_out_dev, float* hn_out_dev, float* logits_out_dev,
+                           float* p_dev, void* stream);
+/* `embed` alone: rows of v_dev (n_rows, L*H) -> logits (n_rows, 2) and / or their softmax (core/models.py:109-128). */
+int vad_nicknet_embed_f32(const float* v_dev, int64_t n_rows, const float* blob_dev, int large,
+                          float* logits_dev, float* p_dev, void* stream);
+
+/*
  * Noise/speech mix ahead of the feature call on the training-data path: the
  * int16 arithmetic of `noise_track.overlay(speech_track, gain_during_overlay=dB)`
  * in add_noise (core/process_data.py:283-297; pydub -> audioop.mul + audioop.add):

@@ -7,7 +7,7 @@ GPU the calls raise ``VadError``.
 """
 from ._lib import VadError, build, init, lib
 from .common import (ALIGN_FRAMES, BATCH_SIZE, FEATURES, FRAME_SIZE, FRAMES, SAMPLE_RATE, SLICE_MAX, STEP_SIZE)
-from .models import MODEL_STACK, DenseNet, Net, set_matrix_mode
+from .models import MODEL_STACK, DenseNet, Net, NickNet, set_matrix_mode
 from .process_data import (add_noise, mfcc_delta_ragged, mfcc_delta_slices, mfcc_delta_stream, overlay, overlay_device,
                            process_test_data, process_test_frames, process_training_data, recording_slices,
                            training_slices)
@@ -18,7 +18,7 @@ from .stream import StreamWorkspace, vad_stream
 from .sharding import HALO_FRAMES, all_gather_posteriors, gather_posteriors, shard_plan, shard_range, window_owner_ranges
 from .synth import synth_audio, synth_stream
 
-__all__ = ['VadError', 'build', 'init', 'lib', 'Net', 'DenseNet', 'MODEL_STACK', 'set_matrix_mode', 'process_test_frames', 'process_test_data', 'recording_slices', 'add_noise',
+__all__ = ['VadError', 'build', 'init', 'lib', 'Net', 'DenseNet', 'NickNet', 'MODEL_STACK', 'set_matrix_mode', 'process_test_frames', 'process_test_data', 'recording_slices', 'add_noise',
            'overlay', 'overlay_device', 'mfcc_delta_slices', 'mfcc_delta_stream', 'mfcc_delta_ragged', 'process_training_data', 'training_slices', 'vad_stream', 'StreamWorkspace',
            'synth_audio', 'metrics', 'DataGenerator', 'fix_frr', 'roc_curve', 'threshold_sweep',
            'synth_stream', 'SAMPLE_RATE', 'FRAME_SIZE', 'FRAMES', 'FEATURES', 'BATCH_SIZE', 'SLICE_MAX',

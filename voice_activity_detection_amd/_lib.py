@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAD_AMD_LIB') or os.path.join(_HERE, 'libvad_amd.so')
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
-SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip', 'overlay.hip', 'sweep.hip']
+SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip', 'nicknet.hip', 'overlay.hip', 'sweep.hip']
 HEADERS = ['vad_internal.h', 'mfcc_device.h', 'rnn_device.h']
 
 # every symbol include/vad_amd.h declares
@@ -107,6 +107,18 @@ def lib():
     L.vad_densenet_forward_f32.restype = ctypes.c_int
     L.vad_densenet_forward_f32.argtypes = [c_void, c_i64, c_i64, c_void, ctypes.c_int, c_void, c_void,
                                            ctypes.c_int, ctypes.c_float, c_void]
+    L.vad_nicknet_blob_floats.restype = ctypes.c_size_t
+    L.vad_nicknet_blob_floats.argtypes = [ctypes.c_int]
+    L.vad_nicknet_tensor_count.restype = ctypes.c_int
+    L.vad_nicknet_tensor_count.argtypes = [ctypes.c_int]
+    L.vad_pack_nicknet_weights.restype = ctypes.c_int
+    L.vad_pack_nicknet_weights.argtypes = L.vad_pack_densenet_weights.argtypes
+    L.vad_nicknet_forward_f32.restype = ctypes.c_int
+    L.vad_nicknet_forward_f32.argtypes = L.vad_densenet_forward_f32.argtypes
+    L.vad_nicknet_stages_f32.restype = ctypes.c_int
+    L.vad_nicknet_stages_f32.argtypes = [c_void, c_i64, c_i64, c_void, c_void, ctypes.c_int] + [c_void] * 6
+    L.vad_nicknet_embed_f32.restype = ctypes.c_int
+    L.vad_nicknet_embed_f32.argtypes = [c_void, c_i64, c_void, ctypes.c_int, c_void, c_void, c_void]
     L.vad_synth_audio_i16.restype = ctypes.c_int
     L.vad_synth_audio_i16.argtypes = [c_void, c_i64, c_i64, ctypes.c_uint32, c_void]
     L.vad_overlay_i16.restype = ctypes.c_int
@@ -127,6 +139,8 @@ def lib():
     L.vad_densenet_forward_rows_f32.restype = ctypes.c_int
     L.vad_densenet_forward_rows_f32.argtypes = [c_void, c_i64, c_void, c_i64, c_void, ctypes.c_int, c_void, c_void,
                                                 ctypes.c_int, ctypes.c_float, c_void]
+    L.vad_nicknet_forward_rows_f32.restype = ctypes.c_int
+    L.vad_nicknet_forward_rows_f32.argtypes = L.vad_densenet_forward_rows_f32.argtypes
     _lib = L
     return L
 

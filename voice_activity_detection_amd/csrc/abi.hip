@@ -72,6 +72,8 @@ extern "C" int vad_init(void) {
     if (rc != VAD_OK) return rc;
     rc = vad::ensure_densenet_attrs();
     if (rc != VAD_OK) return rc;
+    rc = vad::ensure_nicknet_attrs();
+    if (rc != VAD_OK) return rc;
     return vad::ensure_sweep_scratch();
 }
 

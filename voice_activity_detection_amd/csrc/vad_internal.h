@@ -36,6 +36,7 @@ int ensure_mfcc_tables();
 // One-time per-device opt-in of the model kernels that need more than 64 KB of LDS; defined in rnn.hip.
 int ensure_rnn_attrs();
 int ensure_densenet_attrs();   // the same for the stride-1 DenseNet kernels; defined in densenet.hip
+int ensure_nicknet_attrs();    // the same for the conv + GRU model's kernels; defined in nicknet.hip
 
 // Looks up, once per device, the address of the built-in histogram of vad_threshold_sweep_noalloc_f32; sweep.hip.
 int ensure_sweep_scratch();

@@ -323,6 +323,129 @@ class DenseNet(_HipModule):
                                                thr, stream)
 
 
+class _GatedConv(nn.Module):                   # parameter container, core/models.py:180-202
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv1d(in_channels, out_channels, kernel_size=3, dilation=1, padding=1),
+                                  nn.BatchNorm1d(out_channels), nn.Tanh())
+        self.conv_gate = nn.Sequential(nn.Conv1d(in_channels, out_channels, kernel_size=3, dilation=1, padding=1),
+                                       nn.BatchNorm1d(out_channels), nn.Sigmoid())
+
+
+class _BiRNN(nn.Module):                       # parameter container, core/models.py:84-128 (GRU, one direction, fcl)
+    def __init__(self, num_in, num_hidden, large):
+        super().__init__()
+        layers = 2 if large else 1
+        self.rnn = nn.GRU(num_in, num_hidden, num_layers=layers, bidirectional=False, batch_first=True)
+        sz, embed_sz = 18, num_hidden * layers
+        if large:
+            self.embed = nn.Sequential(nn.Linear(embed_sz, sz + 14), nn.BatchNorm1d(sz + 14), nn.Dropout(p=0.2), nn.ReLU(),
+                                       nn.Linear(sz + 14, sz), nn.BatchNorm1d(sz), nn.Dropout(p=0.2), nn.ReLU(),
+                                       nn.Linear(sz, 2))
+        else:
+            self.embed = nn.Sequential(nn.Linear(embed_sz, sz), nn.BatchNorm1d(sz), nn.Dropout(p=0.2), nn.ReLU(),
+                                       nn.Linear(sz, 2))
+
+
+class NickNet(_HipModule):
+    """core/models.py:245-330 in its default configuration (gated convolutions, no residual connections, GRU,
+    one direction, fully connected head); the other constructor switches of the reference are refused.
+
+    The reference's own ``forward`` raises between the GRU and ``embed`` (core/models.py:166-174: 870 columns where
+    ``embed`` takes 58 / 21).  The head input here is the final hidden state of every GRU layer,
+    ``h_n.permute(1, 0, 2).reshape(B, L*H)`` -- the one tensor the GRU returns with ``embed``'s width.  ``stages``
+    returns the outputs of the sub-modules that do run in the reference, for checking them one by one."""
+
+    def __init__(self, large=True, residual_connections=False, gated=True, lstm=False, fcl=True, bidir=False,
+                 frames=FRAMES, features=FEATURES):
+        super().__init__()
+        if residual_connections or not gated or lstm or not fcl or bidir or frames != FRAMES or features != FEATURES:
+            raise NotImplementedError('NickNet is built in its default configuration only: gated=True, '
+                                      'residual_connections=False, lstm=False, fcl=True, bidir=False, 30 x 24 windows')
+        self.large = large
+        self.residual_connections = residual_connections
+        chans = (32, 28, 25, 18) if large else (20, 18, 16)           # core/models.py:264-275
+        cin = features
+        for i, c in enumerate(chans):
+            setattr(self, 'conv%d' % (i + 1), _GatedConv(cin, c))
+            cin = c
+        self.rnn = _BiRNN(cin, cin + 11 if large else cin + 5, large)  # core/models.py:303-304
+
+    def _tensors(self):
+        return [_np32(v) for k, v in self.state_dict().items() if not k.endswith('num_batches_tracked')]
+
+    def _pack(self):
+        L = _lib.lib()
+        arrays = self._tensors()
+        if len(arrays) != L.vad_nicknet_tensor_count(int(self.large)):
+            raise _lib.VadError('unexpected NickNet tensor count %d' % len(arrays))
+        ptrs = (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        n = L.vad_nicknet_blob_floats(int(self.large))
+        blob = np.zeros(n, np.float32)
+        _lib.check(L.vad_pack_nicknet_weights(int(self.large), ptrs, len(arrays), _lib.host_ptr(blob), n))
+        return blob
+
+    def _launch(self, L, x_ptr, n, stride, blob_ptr, p_ptr, d_ptr, mode, thr, stream, matrix_mode=None,
+                workspace=None):
+        return L.vad_nicknet_forward_f32(x_ptr, n, stride, blob_ptr, int(self.large), p_ptr, d_ptr, mode, thr, stream)
+
+    def _launch_rows(self, L, f_ptr, n_rows, r_ptr, n, blob_ptr, p_ptr, d_ptr, mode, thr, stream):
+        return L.vad_nicknet_forward_rows_f32(f_ptr, n_rows, r_ptr, n, blob_ptr, int(self.large), p_ptr, d_ptr, mode,
+                                              thr, stream)
+
+    @property
+    def _dims(self):
+        gru = self.rnn.rnn
+        return gru.input_size, gru.hidden_size, gru.num_layers
+
+    def stages(self, x=None, trunk=None):
+        """Outputs of the sub-modules for a (B,30,24) batch ``x`` -- or, with ``trunk`` (B,C,30) given instead,
+        of the GRU and the head started from that trunk output: dict with ``trunk`` (B,C,30) (core/models.py:308-323),
+        ``seq`` (B,30,H) and ``hn`` (L,B,H) (``net.rnn.rnn(...)``, core/models.py:162), ``logits`` and ``p`` (B,2)."""
+        L = _lib.lib()
+        if (x is None) == (trunk is None):
+            raise ValueError('give exactly one of x and trunk')
+        c, hid, layers = self._dims
+        dev = _cuda_device()
+        src = (x if x is not None else trunk).detach().to(device=dev, dtype=torch.float32).contiguous()
+        if x is not None and (src.dim() != 3 or tuple(src.shape[1:]) != (FRAMES, FEATURES)):
+            raise ValueError('x must be (B,%d,%d)' % (FRAMES, FEATURES))
+        if trunk is not None and (src.dim() != 3 or tuple(src.shape[1:]) != (c, FRAMES)):
+            raise ValueError('trunk must be (B,%d,%d)' % (c, FRAMES))
+        b = src.size(0)
+        out = {'seq': torch.empty((b, FRAMES, hid), device=dev), 'hn': torch.empty((layers, b, hid), device=dev),
+               'logits': torch.empty((b, 2), device=dev), 'p': torch.empty((b, 2), device=dev)}
+        if x is not None:
+            out['trunk'] = torch.empty((b, c, FRAMES), device=dev)
+        if b == 0:
+            return out
+        blob = self._weights_on(dev)
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(L.vad_nicknet_stages_f32(ptr(src if x is not None else None), b, FRAMES * FEATURES,
+                                                ptr(src if trunk is not None else None), ptr(blob), int(self.large),
+                                                ptr(out.get('trunk')), ptr(out['seq']), ptr(out['hn']),
+                                                ptr(out['logits']), ptr(out['p']), _lib.current_stream()))
+        return out
+
+    def embed(self, v):
+        """``net.rnn.embed(v)`` (core/models.py:109-128, eval mode) for rows ``v`` (B, L*H): the logits (B,2)."""
+        L = _lib.lib()
+        _, hid, layers = self._dims
+        dev = _cuda_device()
+        v = v.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if v.dim() != 2 or v.size(1) != hid * layers:
+            raise ValueError('v must be (B,%d)' % (hid * layers))
+        logits = torch.empty((v.size(0), 2), device=dev)
+        if v.size(0):
+            blob = self._weights_on(dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.vad_nicknet_embed_f32(ctypes.c_void_p(v.data_ptr()), v.size(0), ctypes.c_void_p(blob.data_ptr()),
+                                                   int(self.large), ctypes.c_void_p(logits.data_ptr()), None,
+                                                   _lib.current_stream()))
+        return logits
+
+
 def _model_stack():
     # names, descriptions and training kwargs as in core/models.py:465-514
     return {
