@@ -40,7 +40,8 @@ VALU_ISSUE_NS_MEASURED = 1.18                  # ns per wave64 v_add_f32 per SIM
 FRONTEND_BYTES_PER_FRAME = 480 * 2 + 24 * 4          # int16 in, 24 floats out
 FRONTEND_FLOP_PER_FRAME = 64_000                       # 2048-pt rfft + power + mel + DCT + delta
 RESULT_BYTES_PER_WINDOW = 9                            # 2 float posteriors + 1 decision byte
-MODELS = ['gru_large', 'gru_small', 'lstm_large', 'lstm_small', 'gru_h90', 'densenet', 'densenet_large']
+MODELS = ['gru_large', 'gru_small', 'lstm_large', 'lstm_small', 'gru_h90', 'densenet', 'densenet_large', 'nicknet',
+          'nicknet_small']
 
 
 def _rnn_flops(gates, hidden, head_rows, gate_ops):
@@ -63,6 +64,20 @@ def _densenet_flops(c0, layers, growth):
     return stem + rest, 10 * stem + rest
 
 
+def _nicknet_flops(chans, hidden, layers, widths):
+    """The same pair for the conv + GRU hybrid.  A gated convolution layer l (1-based) of a stride-1 stream is a
+    property of the feature row wherever its receptive field stays clear of the window's zero padding: positions
+    l .. 29 - l; only the 2 l positions next to the padding are the window's own.  Algorithmically a window
+    therefore needs 2 l + 1 positions of layer l (its own, and one new row of the shared interior); a batch
+    framework evaluates all 30."""
+    per_pos = [2 * chans[l + 1] * chans[l] * 3 * 2 for l in range(len(chans) - 1)]
+    gru = sum(3 * hidden * ((chans[-1] if g == 0 else hidden) + hidden) * 2 * T for g in range(layers)) + \
+        layers * T * hidden * 12
+    cols = [layers * hidden] + list(widths) + [2]
+    head = sum(cols[i] * cols[i + 1] * 2 for i in range(len(cols) - 1))
+    return sum((2 * (l + 1) + 1) * c for l, c in enumerate(per_pos)) + gru + head, T * sum(per_pos) + gru + head
+
+
 FLOP_PER_WINDOW = {               # model -> (algorithmic for stride-1 windows, PyTorch-equivalent per (30,24) window)
     'gru_large': _rnn_flops(3, 30, 26, 12),
     'gru_small': _rnn_flops(3, 30, 2, 12),
@@ -71,27 +86,32 @@ FLOP_PER_WINDOW = {               # model -> (algorithmic for stride-1 windows, 
     'gru_h90': _rnn_flops(3, 90, 26, 12),          # enlarged GRU, ~100k parameters
     'densenet': _densenet_flops(24, 6, 3),
     'densenet_large': _densenet_flops(48, 8, 4),
+    'nicknet': _nicknet_flops((F, 32, 28, 25, 18), 29, 2, (32, 18)),      # the reference's conv + GRU hybrid, ~30k
+    'nicknet_small': _nicknet_flops((F, 20, 18, 16), 21, 1, (18,)),      # ~10k parameters
 }
 # the kernel that scores stride-1 windows of each model, as rocprofv3 names it (template arguments included)
 MODEL_KERNEL = {'gru_large': 'rnn_stream_kernel<false, true, 15>', 'gru_small': 'rnn_stream_kernel<false, false, 15>',
                 'lstm_large': 'rnn_stream_kernel<true, true, 15>', 'lstm_small': 'rnn_stream_kernel<true, false, 15>',
                 'gru_h90': 'gru_wide_stream_kernel<true, 3, 13>',
-                'densenet': 'densenet_stream_kernel<false>', 'densenet_large': 'densenet_stream_kernel<true>'}
+                'densenet': 'densenet_stream_kernel<false>', 'densenet_large': 'densenet_stream_kernel<true>',
+                'nicknet': 'nicknet_kernel<true>', 'nicknet_small': 'nicknet_kernel<false>'}
 
 
+DEFAULT_MODE = 'f16x6'
+MATRIX_MODE_NAMES = ['f32', 'bf16x6', 'bf16x8', 'bf16x9', 'f16x6', 'f16x4']
 HIDDEN = {'gru_h90': 90}                     # every other recurrent model has the reference's 30 units
 
 
 def split_mode_applies(model):
     """The bf16 split matrix modes apply to the stride-1 GRU / LSTM kernels (30 units, and the wide GRU's
     workspace path); DenseNet always computes on the float32 MFMA."""
-    return not MODEL_KERNEL[model].startswith('densenet')
+    return not MODEL_KERNEL[model].startswith(('densenet', 'nicknet'))
 
 
 def model_peak(model, mode):
     """The float32 flop rate the hardware could sustain on a model's algorithmic work.  float32 MFMA and float32
     vector work share one pipe (157.3 TF).  In the bf16 split modes the recurrent and 26-row head products run as
-    9, 8 or 6 bf16 partial products each on the bf16 matrix pipe, beside the rest of the work (projection, gate
+    9, 8, 6 or 4 bf16 / f16 partial products each on the 16-bit matrix pipe, beside the rest of the work (projection, gate
     math, 2-row head) on the float32 pipe: the slower of the two pipes bounds it."""
     if mode == 'f32' or not split_mode_applies(model):
         return PEAK_FP32_TFLOPS
@@ -109,10 +129,10 @@ def model_kernel(model, mode):
     name = MODEL_KERNEL[model]
     if mode != 'f32' and name.startswith('rnn_stream_kernel'):
         lstm, large = name[name.index('<') + 1:].split(', ')[:2]
-        return 'rnn_stream_split_kernel<%s, %s, %s>' % (lstm, large, mode[-1])
+        return 'rnn_stream_split_kernel<%s, %s, %s, %s>' % (lstm, large, mode[-1], 'true' if mode.startswith('f16') else 'false')
     if mode != 'f32' and name.startswith('gru_wide_stream_kernel'):
         large, ut = name[name.index('<') + 1:].split(', ')[:2]
-        return 'gru_wide_split_kernel<%s, %s, %s, 1>' % (large, ut, mode[-1])
+        return 'gru_wide_split_kernel<%s, %s, %s, 1, %s>' % (large, ut, mode[-1], 'true' if mode.startswith('f16') else 'false')
     return name
 
 
@@ -150,8 +170,9 @@ def make_net(kind):
     torch.manual_seed(1337)
     if kind == 'gru_h90':                              # no class in the reference: GRU(24, 90) + the same heads
         return pkg.Net(large=True, lstm=False, hidden=90)
-    if kind.startswith('densenet'):
-        net = pkg.DenseNet(large=kind.endswith('large'))
+    if kind.startswith(('densenet', 'nicknet')):
+        net = pkg.DenseNet(large=kind.endswith('large')) if kind.startswith('densenet') else \
+            pkg.NickNet(large=not kind.endswith('small'))
         g = torch.Generator().manual_seed(1338)
         with torch.no_grad():
             for m in net.modules():
@@ -168,9 +189,12 @@ def make_net(kind):
 
 def make_models(kind):
     """(product model, CPU oracle model with the same weights): for the checker-side tools and the CPU baseline."""
-    from oracle import models_ref
+    from oracle import models_ref, nicknet_ref
     net = make_net(kind)
-    ref = models_ref.make_model('gru_large', hidden=90) if kind == 'gru_h90' else models_ref.make_model(kind)
+    if kind.startswith('nicknet'):
+        ref = nicknet_ref.NickNetRef(large=not kind.endswith('small'))
+    else:
+        ref = models_ref.make_model('gru_large', hidden=90) if kind == 'gru_h90' else models_ref.make_model(kind)
     ref.load_state_dict(net.state_dict())
     return net, ref.eval()
 
@@ -290,6 +314,8 @@ def compact_record(out):
     if 'f32' in modes:                                  # the strict float32 (fp32 MFMA) figure beside the headline
         c['value_f32_mfma'] = _r(modes['f32']['value'])
         c['ms_per_step_f32_mfma'] = _r(modes['f32']['ms_per_step'])
+    if 'bf16x8' in modes and out.get('matrix_mode') != 'bf16x8':      # the previous rounds' default, for comparison
+        c['value_bf16x8'] = _r(modes['bf16x8']['value'])
     c['config'] = out['config']
     c['x_realtime_per_gpu'] = _r(out['x_realtime_per_gpu'])
     c['roofline'] = roof(out['roofline'])
@@ -307,8 +333,8 @@ def compact_record(out):
                                'frac': _r(rec['kernels']['model']['frac'])}
                         for name, rec in out['configs'].items()}
     if modes:
-        c['matrix_modes'] = {mm: {'value': _r(v['value']), 'model_ms': _r(v['model_kernel_ms']),
-                                  'max_diff_vs_f32': _r(v['max_abs_posterior_diff_vs_f32'], 3)}
+        c['matrix_modes'] = {mm: {'value': _r(v['value'], 4), 'model_ms': _r(v['model_kernel_ms'], 4),
+                                  'max_diff': _r(v['max_abs_posterior_diff_vs_f32'], 2)}
                              for mm, v in modes.items()}
     if out.get('cpu_baseline'):
         b = out['cpu_baseline']
@@ -360,10 +386,11 @@ def main():
     ap.add_argument('--slice', type=int, default=166, help='frames per MFCC slice (reference test path: 166)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
     ap.add_argument('--no-configs', action='store_true', help='time the headline workload only')
-    ap.add_argument('--matrix-mode', default='bf16x8', choices=['f32', 'bf16x6', 'bf16x8', 'bf16x9'],
+    ap.add_argument('--matrix-mode', default=DEFAULT_MODE, choices=MATRIX_MODE_NAMES,
                     help="how the stride-1 GRU/LSTM kernels form float32 products (default: the library's default, "
-                         'bf16x8 = float32 operands split exactly into three bf16, the partial products accumulated '
-                         'in float32 on the bf16 matrix pipe, all but lo * lo, which is under 2^-30 of a product)')
+                         'f16x6 = float32 operands split into three float16 on exact power-of-two scales, the six '
+                         'largest partial products accumulated in float32 on the f16 matrix pipe: under 2^-35 of a '
+                         'product is left out)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -482,9 +509,9 @@ def main():
             'note': 'achieved = algorithmic float32 flops / time, with the per-row work (input projection / DenseNet '
                     'stem) counted once per feature row as stride-1 windows need it; flop_per_window_pytorch counts '
                     'it per (30,24) window as a batch framework does.  peak: 157.3 TF (fp32 MFMA = fp32 vector rate) '
-                    'for float32-MFMA kernels; in the bf16x9 / bf16x8 / bf16x6 matrix modes every float32 product of the '
-                    'recurrence and the 26-row head costs 9 / 8 / 6 bf16 products, so the peak for that work is '
-                    '2500 TF / 9 (8, 6), taken beside the float32 pipe for the rest'}
+                    'for float32-MFMA kernels; in the split matrix modes (bf16x9 / bf16x8 / bf16x6 / f16x6 / f16x4) every '
+                    'float32 product of the recurrence and the 26-row head costs 9 / 8 / 6 / 6 / 4 products of the 16-bit '
+                    'matrix pipe, so the peak for that work is 2500 TF / that count, taken beside the float32 pipe for the rest'}
         fe_gbs = FRONTEND_BYTES_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e9
         fe_tf = FRONTEND_FLOP_PER_FRAME * n_frames / (fe_ms * 1e-3) / 1e12
         fe_pmc = pmc_per_unit(prof, 'mfcc_kernel')
@@ -539,17 +566,17 @@ def main():
                'config': head['config'], 'x_realtime_per_gpu': head['x_realtime_per_gpu'],
                'roofline': head['roofline'], 'roofline_choice': head['roofline_choice'], 'kernels': head['kernels'],
                'matrix_mode': args.matrix_mode,
-               'dtype_note': {'f32': 'float32 MFMA (k-ordered FMA chain)'}.get(
-                   args.matrix_mode, 'f32 operands split exactly into 3 bf16, %s of 9 partial products on the bf16 '
-                                     'MFMA, f32 accumulation' % args.matrix_mode[-1]),
+               'dtype_note': 'float32 MFMA (k-ordered FMA chain)' if args.matrix_mode == 'f32' else
+                             'f32 operands split exactly into 3 %s, %s of 9 partial products on the 16-bit MFMA, f32 '
+                             'accumulation' % ('f16' if args.matrix_mode.startswith('f16') else 'bf16', args.matrix_mode[-1]),
                'dist_backend': (backend if dist else None)}
 
-    if not args.no_configs and args.model == 'gru_large' and args.matrix_mode == 'bf16x8':
+    if not args.no_configs and args.model == 'gru_large' and args.matrix_mode == DEFAULT_MODE:
         # The other configurations of the measurement plan, 3 steps each on the buffers of the headline run:
         # LSTM-small, DenseNet small and large, and the enlarged GRU (hidden 90).  With 8 ranks the enlarged
         # GRU runs at its named size, 10 000 h over the node = 1 250 h (144 GB of int16) per GPU.
         extra = {}
-        for model in ('lstm_small', 'densenet', 'densenet_large', 'gru_h90'):
+        for model in ('lstm_small', 'densenet', 'densenet_large', 'gru_h90', 'nicknet'):
             rec, buffers = run_workload(model, args.hours, 3, 1, buffers)
             extra[model] = rec
         # (BENCH_BIG_WORLD / BENCH_BIG_HOURS rehearse this branch at other sizes)
@@ -582,13 +609,13 @@ def main():
         if rank == 0:
             out['configs'] = extra
 
-    if rank == 0 and world == 1 and args.matrix_mode == 'bf16x8' and \
+    if rank == 0 and world == 1 and args.matrix_mode == DEFAULT_MODE and \
             args.model in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
         # Not part of `value`: the same step in the other matrix modes of the stride-1 GRU / LSTM kernels
         # (vad_set_matrix_mode) -- the float32 MFMA (a k-ordered FMA chain), bf16x9 and bf16x6 -- and how far the
         # posteriors of each mode are from the float32-MFMA ones over every window of the workload.
         alt, ps = {}, {}
-        for mm in ('f32', 'bf16x9', 'bf16x8', 'bf16x6'):
+        for mm in ('f32', 'f16x6', 'f16x4', 'bf16x9', 'bf16x8', 'bf16x6'):
             pkg.set_matrix_mode(mm)
             current_mode[0] = mm
             rec, buffers = run_workload(args.model, args.hours, 3, 1, buffers)

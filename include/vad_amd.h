@@ -214,19 +214,31 @@ int vad_gru_forward_ws_f32(const float* x_dev, int64_t n_windows, int64_t window
  *                      to C and rounded to nearest (measured by tools/probes/mfma_bf16_accum_k32.hip), which
  *                      bounds a K = 32 dot product's error
  *                      by about 68 * 2^-24 * the largest magnitude in the chain (float32 FMA chain: 30 * 2^-24).
- *   VAD_MATRIX_BF16X8  (default) as BF16X9 without the lo * lo partial product: the operands are split by
+ *   VAD_MATRIX_BF16X8  as BF16X9 without the lo * lo partial product: the operands are split by
  *                      truncation, so |lo| < 2^-15 |x| and the dropped term is below 2^-30 of the product it
  *                      belongs to, 1/64 of the rounding unit of a single float32 operation; it adds
  *                      2^-30 * sum |a b| (under 2^-6 * 2^-24 of the chain's magnitude per term) to the bound above.
  *   VAD_MATRIX_F32     v_mfma_f32_32x32x2_f32: a float32 FMA chain in k order, bit-identical to what every other
  *                      path of this library computes (dense batches, other strides, sampled windows).
  *   VAD_MATRIX_BF16X6  as BF16X9 without the three smallest partial products (<= 2^-23 of a product).
+ *   VAD_MATRIX_F16X6   (default) the same construction on float16 operands (v_mfma_f32_16x16x32_f16): float16 has 11 significant
+ *                      bits, so x = hi + mid + lo by round-to-nearest has |mid| <= 2^-12 |x|, |lo| <= 2^-24 |x| and the six
+ *                      largest partial products leave out less than 2^-35 of a product -- the reach of BF16X9 for the
+ *                      instructions of BF16X6.  float16's narrow exponent is handled with powers of two, which round
+ *                      nothing: the hidden state is carried as 2^14 h and the packer multiplies the weights by the
+ *                      largest 2^Sw that keeps them below 65504, so that every operand of magnitude >= 0.5 after scaling
+ *                      -- hidden states from 2^-15, weights from 2^-14 of the largest -- is split exactly (smaller ones are
+ *                      rounded to 2^-25 of the scaled unit); the accumulators hold 2^(14+Sw) times the pre-activations and
+ *                      the gate math multiplies that back out (two multiplies per GRU unit and step, four per LSTM unit).
+ *   VAD_MATRIX_F16X4   hi * hi, hi * mid, mid * hi, mid * mid of the same split: products to 2^-23, four instructions.
  * Other strides, sampled windows, wider GRUs without a workspace and DenseNet always compute as VAD_MATRIX_F32.
  */
 #define VAD_MATRIX_F32 0
 #define VAD_MATRIX_BF16X6 1
 #define VAD_MATRIX_BF16X9 2
 #define VAD_MATRIX_BF16X8 3
+#define VAD_MATRIX_F16X6 4
+#define VAD_MATRIX_F16X4 5
 #define VAD_MATRIX_DEFAULT (-1)   /* per-call argument only: use the process-wide mode */
 int vad_set_matrix_mode(int mode);
 int vad_get_matrix_mode(void);

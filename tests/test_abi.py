@@ -105,7 +105,7 @@ def test_argument_checks_reject_before_any_device_work(L):
         ('vad_gru_forward_f32', (ok, 1, 722, ok, 30, 1, ok, None, 0, f0, None), b'window_stride'),
         ('vad_gru_forward_f32', (odd, 1, 720, ok, 30, 1, ok, None, 0, f0, None), b'16-byte aligned'),
         ('vad_gru_forward_f32', (ok, 1, 720, ok, 30, 1, ok, None, 7, f0, None), b'decision_mode'),
-        ('vad_gru_forward_mode_f32', (ok, 1, 24, ok, 30, 1, ok, None, 0, f0, 4, None, 0, None), b'matrix mode'),
+        ('vad_gru_forward_mode_f32', (ok, 1, 24, ok, 30, 1, ok, None, 0, f0, 6, None, 0, None), b'matrix mode'),
         ('vad_gru_forward_mode_f32', (ok, 1, 24, ok, 30, 1, ok, None, 0, f0, -2, None, 0, None), b'matrix mode'),
         ('vad_gru_forward_mode_f32', (ok, 1, 24, ok, 90, 1, ok, None, 0, f0, 0, None, 64, None), b'null workspace'),
         ('vad_lstm_forward_mode_f32', (ok, 1, 24, ok, 30, 1, ok, None, 0, f0, 17, None), b'matrix mode'),
@@ -149,12 +149,20 @@ def _bf16x3(entry_hi, entry_mid, entry_lo):
     return f(entry_hi) + f(entry_mid) + f(entry_lo)
 
 
+def _f16x3(entry_hi, entry_mid, entry_lo):
+    """The same for three float16 terms."""
+    f = lambda e: np.ascontiguousarray(e).view(np.float16).astype(np.float64)
+    return f(entry_hi) + f(entry_mid) + f(entry_lo)
+
+
 @pytest.mark.parametrize('hidden,lstm', [(30, 0), (30, 1), (17, 0), (90, 0), (40, 0)])
 def test_split_operand_layout(L, hidden, lstm):
     """Host-only: the bf16 (hi, mid, lo) A operands of v_mfma_f32_16x16x32_bf16 that the packer writes sum back
     exactly to the scaled float32 weights, at the rows and k-slots the split kernels read them from: lane 16 q + m
     of entry (tile mt, row half mi, k-block kb) holds tile row 16 mi + m and k-slots 8 q + j = tile rows
-    16 (j >> 2) + 4 q + (j & 3) of tile kb."""
+    16 (j >> 2) + 4 q + (j & 3) of tile kb.  The float16 tables that follow have the same layout and hold the weights
+    times a power of two 2^Sw (the largest that keeps them under 65504); their three terms sum back exactly for scaled
+    magnitudes >= 0.5 and to within 2^-25 below (float16's subnormal grid)."""
     H = hidden
     UT = (H + 31) // 32
     G = 4 if lstm else 3
@@ -174,19 +182,33 @@ def test_split_operand_layout(L, hidden, lstm):
     cb = a_hh + G * UT * UT * 16 * 64
     head = cb + 4 * UT * 2 * 16
     tail = head + 30 * UT * 16 * 64
-    s_hh = tail + (2 * 16 + 2 * 2 * 16 + 4)
+    s_hh = tail + (2 * 16 + 2 * 2 * 16 + 4) + 4              # head tail, then 2^S, 2^-S, 2^Sw, pad
+    up, inv, wscale = (float(v) for v in blob[s_hh - 4: s_hh - 1])
+    assert up * inv == 1.0 and up == wscale * 2.0 ** 14 and np.log2(wscale) == int(np.log2(wscale))
+    biggest = max(np.abs(np.asarray(scale)[:, None, None] * w_hh.reshape(G, H, H)).max(), np.abs(lin1_w).max())
+    assert 32500.0 < biggest * wscale <= 65000.0 or wscale == 2.0 ** 13
     gate_entries = G * 2 * 3 if UT == 1 else 3 * UT * 2 * UT * 3
     s_head = s_hh + gate_entries * 256
     words = blob.view(np.uint16)
     entry = lambda base_floats, index: words[2 * (base_floats + index * 256): 2 * (base_floats + (index + 1) * 256)].reshape(64, 8)
     unit = lambda tile, r: (lambda u: -1 if u < 0 else 32 * tile + u)(_unit_of_tile_row(r, min(32, max(0, H - 32 * tile))))
 
-    def check(e_hi, e_mid, e_lo, value_at):
-        got = _bf16x3(e_hi, e_mid, e_lo)
+    hh_floats = gate_entries * 256
+    head_floats = 30 * 2 * 3 * 256 if UT == 1 else 30 * 2 * UT * 3 * 256
+    assert n == s_head + head_floats + hh_floats + head_floats            # bf16 tables, then the float16 ones
+    h_hh = s_head + head_floats
+    h_head = h_hh + hh_floats
+    def check(e_hi, e_mid, e_lo, value_at, f16=False):
+        got = (_f16x3 if f16 else _bf16x3)(e_hi, e_mid, e_lo)
         for lane in range(64):
             for j in range(8):
-                want = value_at(lane & 15, 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3))
-                assert got[lane, j] == float(want), (lane, j)
+                want = float(value_at(lane & 15, 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3)))
+                if f16:
+                    want = float(np.float32(want) * np.float32(wscale))
+                if f16 and abs(want) < 0.5:
+                    assert abs(got[lane, j] - want) <= 2.0 ** -25, (lane, j)
+                else:
+                    assert got[lane, j] == want, (lane, j)
 
     for g in range(G):
         for mt in range(UT):
@@ -195,13 +217,14 @@ def test_split_operand_layout(L, hidden, lstm):
                     def gate_value(m16, p, g=g, mt=mt, mi=mi, kb=kb):
                         m, u = unit(mt, 16 * mi + m16), unit(kb, p)
                         return np.float32(0.0) if m < 0 or u < 0 else np.float32(scale[g] * float(w_hh[g * H + m, u]))
-                    if UT == 1:
-                        base = (g * 2 + mi) * 3
-                        check(entry(s_hh, base), entry(s_hh, base + 1), entry(s_hh, base + 2), gate_value)
-                    else:
-                        base = ((g * UT + mt) * 2 + mi) * UT + kb
-                        hm = 3 * UT * 2 * UT * 2
-                        check(entry(s_hh, 2 * base), entry(s_hh, 2 * base + 1), entry(s_hh, hm + base), gate_value)
+                    for off, f16 in ((s_hh, False), (h_hh, True)):
+                        if UT == 1:
+                            base = (g * 2 + mi) * 3
+                            check(entry(off, base), entry(off, base + 1), entry(off, base + 2), gate_value, f16)
+                        else:
+                            base = ((g * UT + mt) * 2 + mi) * UT + kb
+                            hm = 3 * UT * 2 * UT * 2
+                            check(entry(off, 2 * base), entry(off, 2 * base + 1), entry(off, hm + base), gate_value, f16)
     for t in (0, 13, 29):
         for mi in range(2):
             for kb in range(UT):
@@ -210,3 +233,4 @@ def test_split_operand_layout(L, hidden, lstm):
                     return np.float32(0.0) if o >= 26 or u < 0 else lin1_w[o, t * H + u]
                 base = (t * 2 + mi) * 3 if UT == 1 else ((t * 2 + mi) * UT + kb) * 3
                 check(entry(s_head, base), entry(s_head, base + 1), entry(s_head, base + 2), head_value)
+                check(entry(h_head, base), entry(h_head, base + 1), entry(h_head, base + 2), head_value, True)

@@ -190,7 +190,7 @@ def test_full_size_stream_properties(vad):
         assert_feat_close(feat[lo:hi, :12].cpu().numpy(), rm, 'mfcc slice %d' % s)
         assert_feat_close(feat[lo:hi, 12:].cpu().numpy(), rd, 'delta slice %d' % s)
     # window independence: posteriors of scattered windows from a materialised (B,30,24) batch, which the
-    # float32-MFMA kernels compute; the stream's default matrix mode (bf16x8) stays within the bar of them and
+    # float32-MFMA kernels compute; the stream's default matrix mode (f16x6) stays within the bar of them and
     # of the oracle, and in the float32 matrix mode the whole stream reproduces them bit for bit
     idx = torch.tensor([0, 1, 31, 32, 255, 256, 4_000_000, 7_777_777, n - 31, n - 30], device='cuda')
     batch = torch.stack([feat[i:i + 30] for i in idx.tolist()])

@@ -80,14 +80,14 @@ def test_ragged_batches_match_oracle(vad, kind, batch):
 @pytest.mark.parametrize('kind', list(NET_KINDS))
 def test_fixture_through_the_stride1_kernels(vad, golden_dir, kind):
     """The reference-generated fixture through the stride-1 GRU / LSTM kernels in every matrix mode (the default,
-    bf16x8, first): the 64 fixture windows are laid end to end as a (1920,24) feature matrix, whose stride-1
+    f16x6, first): the 64 fixture windows are laid end to end as a (1920,24) feature matrix, whose stride-1
     windows 0, 30, 60, ... are exactly the fixture windows."""
     sd, x, y = _fixture(golden_dir, kind)
     net = _make(vad, kind)
     net.load_state_dict(sd)
     feat = torch.from_numpy(x.reshape(-1, 24)).cuda()
-    assert vad.lib().vad_get_matrix_mode() == 3                       # VAD_MATRIX_BF16X8 is the default
-    for mode in ('bf16x8', 'bf16x9', 'bf16x6', 'f32'):
+    assert vad.lib().vad_get_matrix_mode() == 4                       # VAD_MATRIX_F16X6 is the default
+    for mode in ('f16x6', 'f16x4', 'bf16x8', 'bf16x9', 'bf16x6', 'f32'):
         prev = vad.set_matrix_mode(mode)
         try:
             p, _ = net.score(feat, window_stride=24)
@@ -119,8 +119,8 @@ def test_sliding_windows_equal_explicit_windows(vad, kind, f32_matrix_mode):
     # strided windows (STEP_SIZE = 6, core/train.py:54)
     p6, _ = net.score(fdev, window_stride=24 * 6)
     assert torch.equal(p6, p_slide[::6])
-    # the default matrix mode of the stride-1 kernels (bf16x8) holds the same bar against the oracle
-    vad.set_matrix_mode('bf16x8')
+    # the default matrix mode of the stride-1 kernels (f16x6) holds the same bar against the oracle
+    vad.set_matrix_mode('f16x6')
     p_x8, _ = net.score(fdev, window_stride=24)
     assert np.abs(p_x8.cpu().numpy() - y).max() <= ATOL
 
@@ -319,7 +319,7 @@ def test_generator_feeds_models_without_batches(vad):
     assert len(scores['rows'][1]) > 0
 
 
-@pytest.mark.parametrize('mode', ['bf16x8', 'bf16x9', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['bf16x8', 'bf16x9', 'bf16x6', 'f16x6', 'f16x4'])
 @pytest.mark.parametrize('kind', ['gru_large', 'gru_small', 'lstm_large', 'lstm_small'])
 def test_split_bf16_matrix_modes(vad, kind, mode):
     """The stride-1 kernels with the products on the bf16 matrix pipe (float32 operands split exactly into
@@ -363,20 +363,17 @@ def test_split_kernels_at_ragged_window_counts(vad, kind):
     windows = torch.stack([torch.from_numpy(feat_np[i:i + 30]) for i in range(571)])
     with torch.no_grad():
         y = ref(windows).numpy()
-    prev = vad.set_matrix_mode('bf16x8')
-    try:
+    for mode in ('bf16x8', 'f16x6'):
         for n in (1, 15, 16, 17, 31, 32, 33, 191, 192, 193, 255, 256, 257, 571):
             p = torch.full((n + 3, 2), -7.0, device='cuda')
             d = torch.full((n + 3,), 9, dtype=torch.uint8, device='cuda')
-            net.score(feat[:n + 29], window_stride=24, n_windows=n, out=p[:n], decisions=d[:n])
-            assert np.abs(p[:n].cpu().numpy() - y[:n]).max() <= ATOL, n
-            assert bool((p[n:] == -7.0).all()) and bool((d[n:] == 9).all()), n
-            assert bool((d[:n] <= 1).all()), n
-    finally:
-        vad.set_matrix_mode(prev)
+            net.score(feat[:n + 29], window_stride=24, n_windows=n, out=p[:n], decisions=d[:n], matrix_mode=mode)
+            assert np.abs(p[:n].cpu().numpy() - y[:n]).max() <= ATOL, (mode, n)
+            assert bool((p[n:] == -7.0).all()) and bool((d[n:] == 9).all()), (mode, n)
+            assert bool((d[:n] <= 1).all()), (mode, n)
 
 
-@pytest.mark.parametrize('mode', ['bf16x8', 'bf16x9', 'bf16x6'])
+@pytest.mark.parametrize('mode', ['bf16x8', 'bf16x9', 'bf16x6', 'f16x6', 'f16x4'])
 @pytest.mark.parametrize('hidden,large', [(90, True), (90, False), (64, True), (40, False), (33, True)])
 def test_wide_gru_split_kernel(vad, hidden, large, mode):
     """Stride-1 windows of the wide GRU with the products on the bf16 matrix pipe: within the bar of the float32
@@ -595,3 +592,19 @@ def test_matrix_mode_is_a_property_of_the_call(vad):
     assert not torch.equal(a, b) and float((a - b).abs().max()) <= 1e-5
     with pytest.raises(ValueError):
         lstm.score(feat, window_stride=24, matrix_mode='fp8')
+
+
+def test_float16_modes_take_outsized_weights(vad):
+    """The float16 tables ride on a power-of-two scale chosen per model, so a recurrent weight far beyond float16's
+    own range (65504) still goes through the float16 matrix modes: same bar against the float32 kernel."""
+    ref = models_ref.make_model('gru_large')
+    with torch.no_grad():
+        ref.rnn.weight_hh_l0[3, 5] = 7.0e4
+        ref.rnn.weight_hh_l0[40, 2] = -3.0e-7
+    net = _gpu_model(vad, 'gru_large', ref)
+    rng = np.random.default_rng(3)
+    feat = torch.tensor(rng.normal(0, 8, size=(500, 24)).astype(np.float32)).cuda()
+    p32, _ = net.score(feat, window_stride=24, matrix_mode='f32')
+    for mode in ('f16x6', 'f16x4', 'bf16x8'):
+        p, _ = net.score(feat, window_stride=24, matrix_mode=mode)
+        assert bool(torch.isfinite(p).all()) and float((p - p32).abs().max()) <= ATOL, mode

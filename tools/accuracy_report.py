@@ -35,7 +35,7 @@ for kind in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small', 'densenet', '
           % (kind, np.abs(p_same.cpu().numpy() - y).max(), np.abs(p_e2e.cpu().numpy() - y).max(),
              int((d_same.cpu().numpy() != ref_dec).sum()), len(y), int((d_e2e.cpu().numpy() != ref_dec).sum())))
 
-# float32 products on the bf16 matrix pipe (vad_set_matrix_mode) against a float64 evaluation of the same models:
+# float32 products on the bf16 / f16 matrix pipe (vad_set_matrix_mode) against a float64 evaluation of the same models:
 # how far each kernel -- and float32 PyTorch on the CPU -- is from the exact answer
 print('\nerror against float64 evaluation of the same weights (20000 windows):')
 x64 = torch.from_numpy(xw[:20000].astype(np.float64))
@@ -48,9 +48,29 @@ for kind in ('gru_large', 'gru_small', 'lstm_large', 'lstm_small'):
     with torch.no_grad():
         y64 = r.double()(x64).numpy()
     row = ['torch-cpu-f32 %.2e' % np.abs(y32 - y64).max()]
-    for mode in ('f32', 'bf16x9', 'bf16x8', 'bf16x6'):
+    for mode in ('f32', 'bf16x9', 'bf16x8', 'bf16x6', 'f16x6', 'f16x4'):
         pkg.set_matrix_mode(mode)
         p, _ = net.score(fdev, window_stride=24)
         row.append('%s max %.2e mean %.2e' % (mode, np.abs(p.cpu().numpy() - y64).max(), np.abs(p.cpu().numpy() - y64).mean()))
     pkg.set_matrix_mode('f32')
     print('%-12s ' % kind + ' | '.join(row))
+
+# the wide GRU (hidden 90) and a stress case for the float16 split: weights and features scaled down so that most
+# operands lie below 0.5, where float16's subnormal grid (2^-24) rounds them
+print('\nhidden 90 and small-operand stress (weights x 0.05), against float64:')
+for name, scale, hidden in (('gru_h90', 1.0, 90), ('gru_large x0.05', 0.05, 30), ('gru_h90 x0.05', 0.05, 90)):
+    r = models_ref.make_model('gru_large', hidden=hidden)
+    with torch.no_grad():
+        r.rnn.weight_hh_l0.mul_(scale)
+        r.lin1.weight.mul_(scale * 4)
+    net = pkg.Net(large=True, lstm=False, hidden=hidden)
+    net.load_state_dict(r.state_dict())
+    with torch.no_grad():
+        y64 = r.double()(x64[:5000]).numpy()
+    r.float()
+    row = []
+    for mode in ('f32', 'bf16x9', 'bf16x8', 'bf16x6', 'f16x6', 'f16x4'):
+        p, _ = net.score(fdev[:5029], window_stride=24, matrix_mode=mode)
+        e = np.abs(p.cpu().numpy() - y64)
+        row.append('%s max %.2e mean %.2e' % (mode, e.max(), e.mean()))
+    print('%-16s ' % name + ' | '.join(row))

@@ -26,6 +26,8 @@ SYMBOLS = [
     'vad_gru_forward_f32', 'vad_lstm_forward_f32', 'vad_densenet_forward_f32', 'vad_gru_forward_ws_f32', 'vad_gru_workspace_bytes',
     'vad_synth_audio_i16', 'vad_overlay_i16', 'vad_threshold_sweep_f32', 'vad_threshold_sweep_noalloc_f32',
     'vad_set_matrix_mode', 'vad_get_matrix_mode', 'vad_gru_forward_mode_f32', 'vad_lstm_forward_mode_f32', 'vad_gru_forward_rows_f32', 'vad_lstm_forward_rows_f32', 'vad_densenet_forward_rows_f32',
+    'vad_nicknet_blob_floats', 'vad_nicknet_tensor_count', 'vad_pack_nicknet_weights', 'vad_nicknet_forward_f32',
+    'vad_nicknet_forward_rows_f32', 'vad_nicknet_stages_f32', 'vad_nicknet_embed_f32',
 ]
 
 

@@ -43,6 +43,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 
 #include "rnn_device.h"
 
@@ -52,7 +53,7 @@ namespace vad {
 using namespace rnn;
 
 // How the stride-1 GRU / LSTM kernels form their float32 matrix products (vad_set_matrix_mode).
-std::atomic<int> g_matrix_mode{VAD_MATRIX_BF16X8};
+std::atomic<int> g_matrix_mode{VAD_MATRIX_F16X6};
 
 namespace {
 
@@ -237,7 +238,7 @@ struct SplitCfg {
     static constexpr int lds_floats = gi_floats + G * kSplitTile + 4 * 2 * 16;
 };
 
-template <bool LSTM, bool LARGE, int TERMS>
+template <bool LSTM, bool LARGE, int TERMS, bool F16>
 __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_kernel(
     const float* __restrict__ feat, long n_windows, const float* __restrict__ blob, float* __restrict__ p_out,
     uint8_t* __restrict__ dec_out, int mode, float threshold) {
@@ -248,8 +249,11 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
     float* gi = lds;                                             // [tiles * 32 rows][rs]
     float* s_hh = lds + C::gi_floats;                            // [G] split tiles
     float* cb = s_hh + G * kSplitTile;
-    for (int i = threadIdx.x; i < G * kSplitTile; i += C::waves * 64) s_hh[i] = blob[L.s_hh + i];
-    for (int i = threadIdx.x; i < 4 * 2 * 16; i += C::waves * 64) cb[i] = blob[L.cb + i];
+    // float16 modes: the accumulators carry 2^S (rnn_device.h); `up` = 2^S, `inv` = 2^-S from the packer
+    const float up = F16 ? blob[L.tail + kTailScale(LARGE)] : 1.0f, inv = F16 ? blob[L.tail + kTailScale(LARGE) + 1] : 1.0f;
+    for (int i = threadIdx.x; i < G * kSplitTile; i += C::waves * 64) s_hh[i] = blob[(F16 ? L.h_hh : L.s_hh) + i];
+    for (int i = threadIdx.x; i < 4 * 2 * 16; i += C::waves * 64)
+        cb[i] = blob[L.cb + i] * (F16 && !LSTM && i >= 3 * 2 * 16 ? up : 1.0f);          // b_hn starts an accumulator
 
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -270,6 +274,10 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
         f32x16 acc = load16(blob + L.cb + (g * 2 + half) * 16);
 #pragma unroll
         for (int s = 0; s < kKs; ++s) acc = MFMA(blob[L.a_ih + (g * kKs + s) * 64 + lane], xv[s], acc);
+        if (F16 && (LSTM || g < 2)) {                            // the parts a matrix product adds to: times 2^S (exact)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] *= up;
+        }
         float* dst = gi + (tile * 32 + col) * C::rs + g * 32 + 4 * half;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -283,11 +291,16 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
     // share a SIMD (w and w + 4) overlap while they are in different phases. ----
     constexpr int NI = C::ni;
     if (w0 + wave * C::wave_windows >= n_windows) return;       // wave-uniform, after the only barrier
+#if defined(VAD_PRIO_SPLIT)
+    if (VAD_PRIO_SPLIT == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (VAD_PRIO_SPLIT == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
+    if (VAD_PRIO_SPLIT == 3) { if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2); }
+#endif
     const int q = lane >> 4, n = lane & 15;
     const long w_first = w0 + wave * C::wave_windows + n;        // the lane's windows: w_first (and w_first + 16)
     const float* a1 = blob + L.head;
     const u32x4* s_gate = reinterpret_cast<const u32x4*>(s_hh);
-    const u32x4* s_head = reinterpret_cast<const u32x4*>(blob + L.s_head);
+    const u32x4* s_head = reinterpret_cast<const u32x4*>(blob + (F16 ? L.h_head : L.s_head));
     f32x16 h, c, lacc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { h[i] = 0.0f; c[i] = 0.0f; lacc[i] = 0.0f; }
@@ -321,26 +334,28 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
             }
         }
         if (t > 0) {                                             // b holds the split of h_{t-1}
-            if (LARGE) lacc = split_tile_mfma<TERMS, NI>(lacc, s_head + (t - 1) * (kSplitTile / 4), b, lane);
+            if (LARGE) lacc = split_tile_mfma<TERMS, NI, F16>(lacc, s_head + (t - 1) * (kSplitTile / 4), b, lane);
             if (LSTM) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     // five tiles' operand reads hoisted together do not fit the 168 registers of a 12-wave block
                     if (LARGE) __builtin_amdgcn_sched_barrier(0);
-                    acc[g] = split_tile_mfma<TERMS, NI>(acc[g], s_gate + g * (kSplitTile / 4), b, lane);
+                    acc[g] = split_tile_mfma<TERMS, NI, F16>(acc[g], s_gate + g * (kSplitTile / 4), b, lane);
                 }
             } else {
-                acc[0] = split_tile_mfma<TERMS, NI>(acc[0], s_gate + 0 * (kSplitTile / 4), b, lane);
-                acc[1] = split_tile_mfma<TERMS, NI>(acc[1], s_gate + 1 * (kSplitTile / 4), b, lane);
-                acc[3] = split_tile_mfma<TERMS, NI>(acc[3], s_gate + 2 * (kSplitTile / 4), b, lane);
+                acc[0] = split_tile_mfma<TERMS, NI, F16>(acc[0], s_gate + 0 * (kSplitTile / 4), b, lane);
+                acc[1] = split_tile_mfma<TERMS, NI, F16>(acc[1], s_gate + 1 * (kSplitTile / 4), b, lane);
+                acc[3] = split_tile_mfma<TERMS, NI, F16>(acc[3], s_gate + 2 * (kSplitTile / 4), b, lane);
             }
         }
-        gate_update<LSTM, NI>(acc, h, c);
-        split_state<NI>(b, h);                                       // for this step's head and the next step's gates
+        if (F16) gate_update_scaled<LSTM, NI>(acc, h, c, up, inv);
+        else gate_update<LSTM, NI>(acc, h, c);
+        split_state<NI, F16, (TERMS > 4)>(b, h);                     // for this step's head and the next step's gates
         if (!LARGE) split_head_step<NI>(lacc, hw, h);
     }
-    if (LARGE) lacc = split_tile_mfma<TERMS, NI>(lacc, s_head + (kT - 1) * (kSplitTile / 4), b, lane);
-    split_head_epilogue<LARGE, NI>(lacc, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold);
+    if (LARGE) lacc = split_tile_mfma<TERMS, NI, F16>(lacc, s_head + (kT - 1) * (kSplitTile / 4), b, lane);
+    split_head_epilogue<LARGE, NI>(lacc, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold,
+                                   F16 ? (LARGE ? inv : kStateUnscale) : 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,9 +529,12 @@ __global__ __launch_bounds__(256, 1) void gru_wide_kernel(const float* __restric
 
 // gi[row][(g * UT + mt) * 32 + half * 16 + i] = accumulator register i of lane (row, half) after bias + W_ih x_row
 // for gate g (r, z, n-input), unit tile mt: exactly the registers a step of the stream kernel starts from.
+// scale_at >= 0: the float16 modes' 2^S sits at blob[scale_at] and multiplies the r and z parts, which the recurrent
+// products add to (the n-input part is only ever read by the gate math).
 template <int UT>
 __global__ __launch_bounds__(256) void row_project_kernel(const float* __restrict__ feat, long n_rows,
-                                                          const float* __restrict__ blob, float* __restrict__ gi) {
+                                                          const float* __restrict__ blob, float* __restrict__ gi,
+                                                          int scale_at) {
     const NetLayout L = net_layout(false, false, UT);            // a_ih and cb do not depend on the head
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
@@ -534,6 +552,11 @@ __global__ __launch_bounds__(256) void row_project_kernel(const float* __restric
         f32x16 acc = load16(blob + L.cb + (gm * 2 + half) * 16);
 #pragma unroll
         for (int s = 0; s < kKs; ++s) acc = MFMA(blob[L.a_ih + (gm * kKs + s) * 64 + lane], xv[s], acc);
+        if (scale_at >= 0 && gm < 2 * UT) {
+            const float up = blob[scale_at];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] *= up;
+        }
         if (row < n_rows) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -641,7 +664,7 @@ struct WideTile {
     f32x4s v[2][NI];
 };
 
-template <int UT, int NI>
+template <int UT, int NI, bool F16, bool WITH_LO>
 __device__ __forceinline__ void wide_split_state(WideSplitB<UT, NI>& b, const WideTile<NI> (&h)[UT]) {
 #pragma unroll
     for (int kb = 0; kb < UT; ++kb)
@@ -649,32 +672,30 @@ __device__ __forceinline__ void wide_split_state(WideSplitB<UT, NI>& b, const Wi
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) {                            // k-slots 2 jp, 2 jp + 1 = rows (jp >> 1, 2 (jp & 1) ..)
-                const float x0 = h[kb].v[jp >> 1][ni][2 * (jp & 1)], x1 = h[kb].v[jp >> 1][ni][2 * (jp & 1) + 1];
-                const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
-                const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
-                const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
-                const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-                b.hi[kb][ni][jp] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-                b.mid[kb][ni][jp] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-                b.lo[kb][ni][jp] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+                const SplitTerms s = split_pair<F16, WITH_LO>(h[kb].v[jp >> 1][ni][2 * (jp & 1)], h[kb].v[jp >> 1][ni][2 * (jp & 1) + 1]);
+                b.hi[kb][ni][jp] = s.hi;
+                b.mid[kb][ni][jp] = s.mid;
+                b.lo[kb][ni][jp] = s.lo;
             }
 }
 
 // c[ni] += A (hi, mid, lo) . B (k-block kb): the TERMS partial products, smallest first
-template <int UT, int NI, int TERMS>
+template <int UT, int NI, int TERMS, bool F16>
 __device__ __forceinline__ void wide_split_terms(f32x4s (&c)[NI], const u32x4& ah, const u32x4& am, const u32x4& al,
                                                  const WideSplitB<UT, NI>& b, int kb) {
     auto term = [&](const u32x4& at, const u32x4 (&bt)[NI]) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) c[ni] = MFMA_BF16(at, bt[ni], c[ni]);
+        for (int ni = 0; ni < NI; ++ni) c[ni] = mfma_split<F16>(at, bt[ni], c[ni]);
     };
     if (TERMS == 9) term(al, b.lo[kb]);
     if (TERMS >= 8) {
         term(am, b.lo[kb]);
         term(al, b.mid[kb]);
     }
-    term(ah, b.lo[kb]);
-    term(al, b.hi[kb]);
+    if (TERMS >= 6) {
+        term(ah, b.lo[kb]);
+        term(al, b.hi[kb]);
+    }
     term(am, b.mid[kb]);
     term(ah, b.mid[kb]);
     term(am, b.hi[kb]);
@@ -696,44 +717,97 @@ __device__ __forceinline__ void rows_down(f32x4s (&x)[NI], int i) {
     }
 }
 
+// The split A operands in LDS: up to 158 entries of 1 KB, more than the 64 KB an LDS instruction's immediate offset
+// spans.  Three lane bases 64 entries apart, each opaque to the compiler: from a single pointer it forms one
+// address register per distant entry, hoists them all out of the step loop and spills them -- and every reload from
+// scratch waits on the vector-memory counter, i.e. for the projected-row loads still in flight from the last step.
+typedef const __attribute__((address_space(3))) u32x4* lds_u4_ptr;
+
+struct WideSplitA {
+    lds_u4_ptr b[3];
+};
+
+__device__ __forceinline__ WideSplitA wide_split_a(const float* lds, int lane) {
+    WideSplitA a;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        unsigned at = (unsigned)(__UINTPTR_TYPE__)((lds_u4_ptr)lds + lane + k * 64 * 64);
+        asm volatile("" : "+v"(at));
+        a.b[k] = (lds_u4_ptr)(__UINTPTR_TYPE__)at;
+    }
+    return a;
+}
+
+__device__ __forceinline__ u32x4 wide_split_entry(const WideSplitA& a, int e) {
+    return e < 64 ? a.b[0][e * 64] : (e < 128 ? a.b[1][(e - 64) * 64] : a.b[2][(e - 128) * 64]);
+}
+
 template <int NI>
 struct WideSplitCfg {
     static constexpr int waves = 8 / NI;                         // per block: one or two per SIMD
     static constexpr int wave_windows = 16 * NI;
 };
 
-template <bool LARGE, int UT, int TERMS, int NI>
+// Diagnostic build only (-DVAD_TIMELINE=<block>): s_memtime stamps of the two waves that share SIMD 0 of one block, at
+// the phase boundaries of every step, read back through vad_debug_timeline (tools/timeline_wide.py).
+#if defined(VAD_TIMELINE)
+constexpr int kTlStamps = 16;
+__device__ unsigned long long g_timeline[2][kT][kTlStamps];
+#define TL_STAMP(k)                                                                                       \
+    do {                                                                                                  \
+        const unsigned long long tl_now = __builtin_amdgcn_s_memtime();                                   \
+        if (blockIdx.x == VAD_TIMELINE && (threadIdx.x & 255) == 0) g_timeline[threadIdx.x >> 8][t][k] = tl_now; \
+    } while (0)
+#else
+#define TL_STAMP(k)
+#endif
+
+template <bool LARGE, int UT, int TERMS, int NI, bool F16>
 __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_kernel(
     const float* __restrict__ gi, long n_windows, const float* __restrict__ blob, float* __restrict__ p_out,
     uint8_t* __restrict__ dec_out, int mode, float threshold) {
     using C = WideSplitCfg<NI>;
     extern __shared__ __align__(16) float lds[];
     const NetLayout L = net_layout(false, LARGE, UT);
-    constexpr int kLdsEntries = wide_split_lds_entries(UT);
     constexpr int kHm = wide_split_hm_entries(UT);
-    const u32x4* a_glob = reinterpret_cast<const u32x4*>(blob + L.s_hh);
+    constexpr int kLdsEntries = TERMS > 4 ? wide_split_lds_entries(UT) : kHm;      // four products: no lo terms
+    const u32x4* a_glob = reinterpret_cast<const u32x4*>(blob + (F16 ? L.h_hh : L.s_hh));
     {
         u32x4* dst = reinterpret_cast<u32x4*>(lds);
         for (int i = threadIdx.x; i < kLdsEntries * 64; i += blockDim.x) dst[i] = a_glob[i];
         float* cbw = lds + kLdsEntries * kSplitEntry;
-        for (int i = threadIdx.x; i < 4 * UT * 32; i += blockDim.x) cbw[i] = blob[L.cb + i];
+        for (int i = threadIdx.x; i < 4 * UT * 32; i += blockDim.x)
+            cbw[i] = blob[L.cb + i] * (F16 && i >= 3 * UT * 32 ? blob[L.tail + kTailScale(LARGE)] : 1.0f);   // b_hn
     }
     __syncthreads();
-    const u32x4* a_lds = reinterpret_cast<const u32x4*>(lds);
     const float* cb = lds + kLdsEntries * kSplitEntry;
-    const u32x4* a_head = reinterpret_cast<const u32x4*>(blob + L.s_head);
+    const u32x4* a_head = reinterpret_cast<const u32x4*>(blob + (F16 ? L.h_head : L.s_head));
     const float* a1 = blob + L.head;
 
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, n = lane & 15;
     const long tile = (long)blockIdx.x * C::waves + (threadIdx.x >> 6);
     if (tile * C::wave_windows >= n_windows) return;             // wave-uniform, after the only barrier
+#if defined(VAD_PRIO_WIDE)
+    if (VAD_PRIO_WIDE == 1 && (threadIdx.x >> 6) >= C::waves / 2) __builtin_amdgcn_s_setprio(1);
+    if (VAD_PRIO_WIDE == 2 && (threadIdx.x >> 6) < C::waves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+    const float up = F16 ? blob[L.tail + kTailScale(LARGE)] : 1.0f, inv = F16 ? blob[L.tail + kTailScale(LARGE) + 1] : 1.0f;
+    const WideSplitA a_lds = wide_split_a(lds, lane);
     const long w_first = tile * C::wave_windows + n;             // the lane's windows: w_first (and w_first + 16)
     const long last_row = n_windows + kT - 2;                    // the workspace holds n_windows + 29 rows
     constexpr int kRow = 3 * UT * 32;                            // floats per projected row
     // tile rows 16 mi + 4 q + i of a 32-row image stored per lane half (hh, element): hh = q & 1, elements
     // 4 (2 mi + (q >> 1)) + i, i.e. float offset 16 hh + that
     const int chunk = 16 * split_image_half(q) + split_image_elem(q, 0);            // mi = 0; mi = 1 is 8 floats on
+    // One opaque base each for the lane's b_hn biases in LDS and for the operand entries that stay in global memory: left
+    // to itself the compiler keeps one address register (pair) per tile and entry alive across the step loop.
+    typedef const __attribute__((address_space(3))) f32x4s* lds_f4s_ptr;
+    unsigned cb_at = (unsigned)(__UINTPTR_TYPE__)((const __attribute__((address_space(3))) float*)(cb + 3 * UT * 32 + chunk));
+    asm volatile("" : "+v"(cb_at));
+    typedef const __attribute__((address_space(1))) u32x4* global_u4_ptr;
+    global_u4_ptr far_base = (global_u4_ptr)(a_glob + (size_t)kLdsEntries * 64 + lane);
+    asm volatile("" : "+v"(far_base));
 
     WideTile<NI> h[UT], lacc, row[3 * UT];
 #pragma unroll
@@ -762,11 +836,27 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
         // the row the wave's last window consumes at the next step
         const long rn = tile * C::wave_windows + (C::wave_windows - 1) + t + 1;
         const float* nxt = gi + (rn < last_row ? rn : last_row) * kRow + chunk;
+        auto next_rows = [&](int mt) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                WideTile<NI>& rv = row[g * UT + mt];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rows_down<NI>(rv.v[mi], i);
+                if (n == 15) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        rv.v[mi][NI - 1] = *reinterpret_cast<const f32x4s*>(nxt + (g * UT + mt) * 32 + 8 * mi);
+                }
+            }
+        };
         SplitHeadWeights hw[UT];                                 // 2-row head: vector ALU, float32 weights
         if (!LARGE) {
 #pragma unroll
             for (int kb = 0; kb < UT; ++kb) split_head_load(hw[kb], a1 + kb * kHk * 64, t * UT, lane);
         }
+        TL_STAMP(0);
 #pragma unroll
         for (int mt = 0; mt < UT; ++mt) {
             WideTile<NI> acc[4];
@@ -774,71 +864,84 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
             for (int g = 0; g < 3; ++g) acc[g] = row[g * UT + mt];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {                     // b_hn
-                const f32x4s v = *reinterpret_cast<const f32x4s*>(cb + (3 * UT + mt) * 32 + chunk + 8 * mi);
+                const f32x4s v = *(lds_f4s_ptr)(__UINTPTR_TYPE__)(cb_at + (mt * 32 + 8 * mi) * 4);
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[3].v[mi][ni] = v;
             }
             if (t > 0) {
-                // the entries that LDS has no room for (the tail of the last gate's lo terms): requested before the
-                // tile's matrix work, used at its end
+                // the entries that LDS has no room for (the tail of the last gate's lo terms): requested a gate ahead of
+                // the one that uses them
                 u32x4 far[2][UT];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int kb = 0; kb < UT; ++kb) {
-                        const int e = kHm + wide_split_base(UT, 2, mt, mi, kb);
-                        if (e >= kLdsEntries) far[mi][kb] = a_glob[e * 64 + lane];
-                    }
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     WideTile<NI>& dst = acc[g == 2 ? 3 : g];
                     __builtin_amdgcn_sched_barrier(0);           // one gate's operand reads at a time
+                    if (g == 1) {
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
+                        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                            for (int kb = 0; kb < UT; ++kb) {
+                                const int e = kHm + wide_split_base(UT, 2, mt, mi, kb);
+                                if (TERMS > 4 && e >= kLdsEntries) far[mi][kb] = far_base[(e - kLdsEntries) * 64];
+                            }
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        if (F16 && mi) __builtin_amdgcn_sched_barrier(0);   // half a gate's operand reads at a time
 #pragma unroll
                         for (int kb = 0; kb < UT; ++kb) {
                             const int base = wide_split_base(UT, g, mt, mi, kb);
-                            const u32x4 ah = a_lds[(base * 2 + 0) * 64 + lane], am = a_lds[(base * 2 + 1) * 64 + lane];
-                            const u32x4 al = kHm + base < kLdsEntries ? a_lds[(kHm + base) * 64 + lane] : far[mi][kb];
-                            wide_split_terms<UT, NI, TERMS>(dst.v[mi], ah, am, al, b, kb);
+                            const u32x4 ah = wide_split_entry(a_lds, base * 2 + 0), am = wide_split_entry(a_lds, base * 2 + 1);
+                            u32x4 al = ah;
+                            if (TERMS > 4) al = kHm + base < kLdsEntries ? wide_split_entry(a_lds, kHm + base) : far[mi][kb];
+                            wide_split_terms<UT, NI, TERMS, F16>(dst.v[mi], ah, am, al, b, kb);
                         }
+                    }
                 }
             }
+            TL_STAMP(1 + 4 * mt);                               // matrix work issued
+#if defined(VAD_TIMELINE)
+            asm volatile("" : "+v"(acc[0].v[0][0]), "+v"(acc[1].v[0][0]), "+v"(acc[3].v[1][0]));   // results have arrived
+            TL_STAMP(2 + 4 * mt);
+#endif
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float r = sigmoid_pre(acc[0].v[mi][ni][i]);
-                        const float z = sigmoid_pre(acc[1].v[mi][ni][i]);
-                        const float nn = tanh_pre(fmaf(r, acc[3].v[mi][ni][i], acc[2].v[mi][ni][i]));
+                        float z, nn;
+                        if (F16) {                               // accumulators times 2^S, state times 2^14 (rnn_device.h)
+                            const float r_inv = __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(acc[0].v[mi][ni][i] * inv), up, up));
+                            z = sigmoid_pre(acc[1].v[mi][ni][i] * inv);
+                            nn = fmaf(-2.0f * kStateScale, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(
+                                          fmaf(r_inv, acc[3].v[mi][ni][i], acc[2].v[mi][ni][i]))), kStateScale);
+                        } else {
+                            const float r = sigmoid_pre(acc[0].v[mi][ni][i]);
+                            z = sigmoid_pre(acc[1].v[mi][ni][i]);
+                            nn = tanh_pre(fmaf(r, acc[3].v[mi][ni][i], acc[2].v[mi][ni][i]));
+                        }
                         h[mt].v[mi][ni][i] = fmaf(z, h[mt].v[mi][ni][i] - nn, nn);   // in place: the products read the split copy
                     }
-            if (t + 1 < kT) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    WideTile<NI>& rv = row[g * UT + mt];
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) rows_down<NI>(rv.v[mi], i);
-                    if (n == 15) {                               // in flight until the next step
-#pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
-                            rv.v[mi][NI - 1] = *reinterpret_cast<const f32x4s*>(nxt + (g * UT + mt) * 32 + 8 * mi);
-                    }
-                }
-            }
+            // The tile's rows move down a lane and the last window's next row is requested: in flight until the next
+            // step.  The last tile's request waits until the head is done: the head's operands come from global memory
+            // too, the memory counter retires in order, and waiting for them right after this request would mean
+            // waiting for a row that is not needed for another two thirds of a step.
+            TL_STAMP(3 + 4 * mt);                               // gate math done
+            if (t + 1 < kT && mt + 1 < UT) next_rows(mt);
+            TL_STAMP(4 + 4 * mt);
         }
-        wide_split_state<UT, NI>(b, h);                          // for this step's head and the next step's gates
+        if (F16) __builtin_amdgcn_sched_barrier(0);              // (the conversions interleaved with the gate math spill)
+        wide_split_state<UT, NI, F16, (TERMS > 4)>(b, h);         // for this step's head and the next step's gates
+        TL_STAMP(13);
         if (LARGE) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int kb = 0; kb < UT; ++kb) {
+                    if (F16) __builtin_amdgcn_sched_barrier(0);      // one k-block's operand requests at a time
                     const u32x4* e = a_head + (size_t)(((t * 2 + mi) * UT + kb) * 3) * 64 + lane;
-                    wide_split_terms<UT, NI, TERMS>(lacc.v[mi], e[0], e[64], e[128], b, kb);
+                    wide_split_terms<UT, NI, TERMS, F16>(lacc.v[mi], e[0], e[64], TERMS > 4 ? e[128] : e[0], b, kb);
                 }
         } else {
 #pragma unroll
@@ -853,6 +956,10 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
                             head2[ni][1] = fmaf(hw[kb].w[4 * mi + i].y, h[kb].v[mi][ni][i], head2[ni][1]);
                         }
         }
+        __builtin_amdgcn_sched_barrier(0);                       // keep the request below the head's waits
+        TL_STAMP(14);
+        if (t + 1 < kT) next_rows(UT - 1);
+        TL_STAMP(15);
     }
     // epilogue in the layout split_head_epilogue reads (element (mi, ni, i) = split_index; 2-row head: elements 2 ni, 2 ni + 1)
     f32x16 out;
@@ -872,7 +979,23 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
             out[2 * ni + 1] = head2[ni][1];
         }
     }
-    split_head_epilogue<LARGE, NI>(out, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold);
+    split_head_epilogue<LARGE, NI>(out, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold,
+                                   F16 ? (LARGE ? inv : kStateUnscale) : 1.0f);
+}
+
+// The split matrix modes as compile-time (partial products, float16 operands) pairs.
+constexpr int kSplitModes[] = {VAD_MATRIX_BF16X6, VAD_MATRIX_BF16X9, VAD_MATRIX_BF16X8, VAD_MATRIX_F16X6, VAD_MATRIX_F16X4};
+
+template <typename F>
+void dispatch_split_mode(int matrix_mode, F&& f) {
+    using std::integral_constant;
+    switch (matrix_mode) {
+        case VAD_MATRIX_BF16X9: f(integral_constant<int, 9>{}, std::false_type{}); break;
+        case VAD_MATRIX_BF16X8: f(integral_constant<int, 8>{}, std::false_type{}); break;
+        case VAD_MATRIX_BF16X6: f(integral_constant<int, 6>{}, std::false_type{}); break;
+        case VAD_MATRIX_F16X6: f(integral_constant<int, 6>{}, std::true_type{}); break;
+        default: f(integral_constant<int, 4>{}, std::true_type{}); break;      // VAD_MATRIX_F16X4
+    }
 }
 
 template <typename K>
@@ -890,18 +1013,35 @@ int allow_wide() {
     return allow_lds(&gru_wide_stream_kernel<LARGE, UT, KL>, L.head - L.a_hh);
 }
 
-constexpr int wide_split_lds_floats(int ut) { return wide_split_lds_entries(ut) * kSplitEntry + 4 * ut * 32; }
+constexpr int wide_split_lds_floats(int ut, int terms) {
+    return (terms > 4 ? wide_split_lds_entries(ut) : wide_split_hm_entries(ut)) * kSplitEntry + 4 * ut * 32;
+}
 
 constexpr int kWideSplitNi = 1;       // window halves per lane of gru_wide_split_kernel: 16 windows per wave, two waves per SIMD
                                       // (2 = 32 windows per wave, one wave per SIMD with all 512 registers: measured 199 vs 148 ms)
 
 template <bool LARGE, int UT>
 int allow_wide_split() {
-    int rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, 9, kWideSplitNi>, wide_split_lds_floats(UT));
-    if (rc != VAD_OK) return rc;
-    rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, 8, kWideSplitNi>, wide_split_lds_floats(UT));
-    if (rc != VAD_OK) return rc;
-    return allow_lds(&gru_wide_split_kernel<LARGE, UT, 6, kWideSplitNi>, wide_split_lds_floats(UT));
+    int rc = VAD_OK;
+    for (int mode : kSplitModes)
+        dispatch_split_mode(mode, [&](auto terms, auto f16) {
+            if (rc == VAD_OK)
+                rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, decltype(terms)::value, kWideSplitNi, decltype(f16)::value>,
+                               wide_split_lds_floats(UT, decltype(terms)::value));
+        });
+    return rc;
+}
+
+template <bool LSTM, bool LARGE>
+int allow_stream_split() {
+    int rc = VAD_OK;
+    for (int mode : kSplitModes)
+        dispatch_split_mode(mode, [&](auto terms, auto f16) {
+            if (rc == VAD_OK)
+                rc = allow_lds(&rnn_stream_split_kernel<LSTM, LARGE, decltype(terms)::value, decltype(f16)::value>,
+                               SplitCfg<LSTM>::lds_floats);
+        });
+    return rc;
 }
 
 }  // namespace
@@ -924,18 +1064,9 @@ int ensure_rnn_attrs() {
     if ((rc = allow_lds(&rnn_stream_kernel<false, true, 16>, StreamCfg<false>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_kernel<true, false, 16>, StreamCfg<true>::lds_floats))) return rc;
     if ((rc = allow_lds(&rnn_stream_kernel<true, true, 16>, StreamCfg<true>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<false, false, 6>, SplitCfg<false>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 6>, SplitCfg<false>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 6>, SplitCfg<true>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<true, true, 6>, SplitCfg<true>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<false, false, 8>, SplitCfg<false>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 8>, SplitCfg<false>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 8>, SplitCfg<true>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<true, true, 8>, SplitCfg<true>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<false, false, 9>, SplitCfg<false>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<false, true, 9>, SplitCfg<false>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<true, false, 9>, SplitCfg<true>::lds_floats))) return rc;
-    if ((rc = allow_lds(&rnn_stream_split_kernel<true, true, 9>, SplitCfg<true>::lds_floats))) return rc;
+    if ((rc = allow_stream_split<false, false>()) || (rc = allow_stream_split<false, true>()) ||
+        (rc = allow_stream_split<true, false>()) || (rc = allow_stream_split<true, true>()))
+        return rc;
     if ((rc = allow_wide<false, 2, 13>()) || (rc = allow_wide<true, 2, 13>()) || (rc = allow_wide<false, 3, 13>()) ||
         (rc = allow_wide<true, 3, 13>()) || (rc = allow_wide<false, 2, 16>()) || (rc = allow_wide<true, 2, 16>()) ||
         (rc = allow_wide<false, 3, 16>()) || (rc = allow_wide<true, 3, 16>()))
@@ -970,31 +1101,27 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
         // chunk's projection from overwriting rows still in use)
         const long chunk = ws_rows - (kT - 1);
         const size_t lds_bytes = (size_t)(L.head - L.a_hh) * sizeof(float);
-        const size_t split_lds_bytes = (size_t)wide_split_lds_floats(UT) * sizeof(float);
         for (long w0 = 0; w0 < n_windows; w0 += chunk) {
             const long nw = n_windows - w0 < chunk ? n_windows - w0 : chunk;
             const long rows = nw + kT - 1;
             const long pblocks = (rows + 127) / 128, blocks = (nw + per_block - 1) / per_block;
             VAD_REQUIRE(pblocks <= 0x7FFFFFFFL && blocks <= 0x7FFFFFFFL, "too many windows for one launch");
+            const bool f16 = matrix_mode == VAD_MATRIX_F16X6 || matrix_mode == VAD_MATRIX_F16X4;
             hipLaunchKernelGGL((row_project_kernel<UT>), dim3((unsigned)pblocks), dim3(256), 0, st, x + w0 * kF, rows, blob,
-                               ws.ptr);
+                               ws.ptr, f16 ? L.tail + kTailScale(LARGE) : -1);
             using SC = WideSplitCfg<kWideSplitNi>;
             const long sblocks = (nw + SC::waves * SC::wave_windows - 1) / (SC::waves * SC::wave_windows);
-            if (matrix_mode == VAD_MATRIX_BF16X9)
-                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 9, kWideSplitNi>), dim3((unsigned)sblocks),
-                                   dim3(64 * SC::waves), split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0,
-                                   dec ? dec + w0 : nullptr, mode, threshold);
-            else if (matrix_mode == VAD_MATRIX_BF16X8)
-                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 8, kWideSplitNi>), dim3((unsigned)sblocks),
-                                   dim3(64 * SC::waves), split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0,
-                                   dec ? dec + w0 : nullptr, mode, threshold);
-            else if (matrix_mode == VAD_MATRIX_BF16X6)
-                hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, 6, kWideSplitNi>), dim3((unsigned)sblocks),
-                                   dim3(64 * SC::waves), split_lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0,
-                                   dec ? dec + w0 : nullptr, mode, threshold);
-            else
+            if (matrix_mode == VAD_MATRIX_F32)
                 hipLaunchKernelGGL((gru_wide_stream_kernel<LARGE, UT, KL>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
                                    lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+            else
+                dispatch_split_mode(matrix_mode, [&](auto terms, auto f16) {
+                    constexpr int kTerms = decltype(terms)::value;
+                    hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, kTerms, kWideSplitNi, decltype(f16)::value>),
+                                       dim3((unsigned)sblocks), dim3(64 * SC::waves),
+                                       (size_t)wide_split_lds_floats(UT, kTerms) * sizeof(float), st, ws.ptr, nw, blob,
+                                       p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+                });
             VAD_HIP_CHECK(hipGetLastError());
         }
         return VAD_OK;
@@ -1030,15 +1157,11 @@ int launch_ks(const float* x, long n_windows, WindowMap wm, const float* blob, f
         const size_t lds_bytes = (size_t)C::lds_floats * sizeof(float);
         const long blocks = (n_windows + C::windows - 1) / C::windows;
         VAD_REQUIRE(blocks <= 0x7FFFFFFFL, "too many windows for one launch");
-        if (matrix_mode == VAD_MATRIX_BF16X9)
-            hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, 9>), dim3((unsigned)blocks), dim3(C::waves * 64),
-                               lds_bytes, st, x, n_windows, blob, p, dec, mode, threshold);
-        else if (matrix_mode == VAD_MATRIX_BF16X8)
-            hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, 8>), dim3((unsigned)blocks), dim3(C::waves * 64),
-                               lds_bytes, st, x, n_windows, blob, p, dec, mode, threshold);
-        else
-            hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, 6>), dim3((unsigned)blocks), dim3(C::waves * 64),
-                               lds_bytes, st, x, n_windows, blob, p, dec, mode, threshold);
+        dispatch_split_mode(matrix_mode, [&](auto terms, auto f16) {
+            hipLaunchKernelGGL((rnn_stream_split_kernel<LSTM, LARGE, decltype(terms)::value, decltype(f16)::value>),
+                               dim3((unsigned)blocks), dim3(C::waves * 64), lds_bytes, st, x, n_windows, blob, p, dec, mode,
+                               threshold);
+        });
         VAD_HIP_CHECK(hipGetLastError());
         return VAD_OK;
     }
@@ -1076,7 +1199,8 @@ int launch(const float* x, long n_windows, WindowMap wm, const float* blob, int 
 }  // namespace
 
 static bool valid_matrix_mode(int m) {
-    return m == VAD_MATRIX_F32 || m == VAD_MATRIX_BF16X6 || m == VAD_MATRIX_BF16X9 || m == VAD_MATRIX_BF16X8;
+    return m == VAD_MATRIX_F32 || m == VAD_MATRIX_BF16X6 || m == VAD_MATRIX_BF16X9 || m == VAD_MATRIX_BF16X8 ||
+           m == VAD_MATRIX_F16X6 || m == VAD_MATRIX_F16X4;
 }
 
 int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, const float* blob, int hidden, int large,
@@ -1113,6 +1237,33 @@ int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, cons
 
 }  // namespace vad
 
+namespace vad {
+namespace {
+// Host twin of split_pair: x -> the three 16-bit terms (hi, mid, lo), bfloat16 by truncation or float16 by
+// round-to-nearest; *finite is cleared when a float16 term overflows.
+inline void split3_host(float x, bool f16, uint16_t out[3], bool* finite) {
+    float r = x;
+    for (int term = 0; term < 3; ++term) {
+        if (f16) {
+            const _Float16 h = (_Float16)r;
+            memcpy(&out[term], &h, 2);
+            const float back = (float)h;
+            if (!(back - back == 0.0f)) *finite = false;
+            r -= back;
+        } else {
+            uint32_t bits;
+            memcpy(&bits, &r, 4);
+            const uint32_t hb = bits & 0xFFFF0000u;
+            float hi;
+            memcpy(&hi, &hb, 4);
+            out[term] = (uint16_t)(hb >> 16);
+            r -= hi;
+        }
+    }
+}
+}  // namespace
+}  // namespace vad
+
 extern "C" int vad_set_matrix_mode(int mode) {
     VAD_REQUIRE(vad::valid_matrix_mode(mode), "unknown matrix mode %d", mode);
     vad::g_matrix_mode.store(mode, std::memory_order_relaxed);
@@ -1120,6 +1271,14 @@ extern "C" int vad_set_matrix_mode(int mode) {
 }
 
 extern "C" int vad_get_matrix_mode(void) { return vad::g_matrix_mode.load(std::memory_order_relaxed); }
+
+#if defined(VAD_TIMELINE)
+extern "C" int vad_debug_timeline(unsigned long long* out_host) {
+    VAD_HIP_CHECK(hipDeviceSynchronize());
+    VAD_HIP_CHECK(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(vad::g_timeline), sizeof(vad::g_timeline)));
+    return 2 * vad::rnn::kT * vad::kTlStamps;
+}
+#endif
 
 extern "C" size_t vad_net_blob_floats(int lstm, int large, int hidden) {
     if (hidden < 1 || hidden > (lstm ? vad::kHp : 3 * vad::kHp)) return 0;
@@ -1208,90 +1367,87 @@ extern "C" int vad_pack_net_weights(int lstm, int large, int hidden, const float
         tail[0] = lin_b[0];
         tail[1] = lin_b[1];
     }
-    if (UT == 1) {
-        // bf16 (hi, mid, lo) images of the float32 A operands above as v_mfma_f32_16x16x32_bf16 A operands: sub-tile
-        // mi, lane l = 16 q + m holds tile row 16 mi + m, k-slots 8 q + j = tile rows split_row_of_k_slot(q, j); in the
-        // float32 image tile row p is k-step (p & 3) + 4 (p >> 3) of lane half (p >> 2) & 1
-        auto split_tile = [&](const float* a16, float* dst) {      // a16: [16][64] floats -> [2][3][64][8 bf16]
-            uint16_t* out = reinterpret_cast<uint16_t*>(dst);
-            for (int mi = 0; mi < 2; ++mi)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int m = 16 * mi + (lane & 15), p = split_row_of_k_slot(lane >> 4, j);
-                        const float x = a16[((p & 3) + 4 * (p >> 3)) * 64 + m + 32 * ((p >> 2) & 1)];
-                        uint32_t bits;
-                        memcpy(&bits, &x, 4);
-                        const uint32_t hb = bits & 0xFFFF0000u;
-                        float hi;
-                        memcpy(&hi, &hb, 4);
-                        const float r1 = x - hi;
-                        memcpy(&bits, &r1, 4);
-                        const uint32_t mb = bits & 0xFFFF0000u;
-                        float mid;
-                        memcpy(&mid, &mb, 4);
-                        const float r2 = r1 - mid;
-                        memcpy(&bits, &r2, 4);
-                        out[(((mi * 3 + 0) * 64 + lane) * 8) + j] = (uint16_t)(hb >> 16);
-                        out[(((mi * 3 + 1) * 64 + lane) * 8) + j] = (uint16_t)(mb >> 16);
-                        out[(((mi * 3 + 2) * 64 + lane) * 8) + j] = (uint16_t)(bits >> 16);
-                    }
-        };
-        for (int g = 0; g < G; ++g) split_tile(blob + L.a_hh + g * kHk * 64, blob + L.s_hh + g * kSplitTile);
-        for (int t = 0; t < kT; ++t) split_tile(blob + L.head + t * kHk * 64, blob + L.s_head + t * kSplitTile);
-    } else {
-        // wide GRU: bf16 (hi, mid, lo) A operands of v_mfma_f32_16x16x32_bf16.  Entry (rows 16 mi .. + 15 of unit
-        // tile mt, k-block kb): lane l = 16 q + m holds tile row 16 mi + m of tile mt and, as k-slots 8 q + j, the tile
-        // rows split_row_of_k_slot(q, j) of tile kb (rnn_device.h); rows and slots that carry no unit stay zero.
-        auto put = [&](float x, uint16_t* e_hi, uint16_t* e_mid, uint16_t* e_lo, int at) {
-            uint32_t bits;
-            memcpy(&bits, &x, 4);
-            const uint32_t hb = bits & 0xFFFF0000u;
-            float hi;
-            memcpy(&hi, &hb, 4);
-            const float r1 = x - hi;
-            memcpy(&bits, &r1, 4);
-            const uint32_t mb = bits & 0xFFFF0000u;
-            float mid;
-            memcpy(&mid, &mb, 4);
-            const float r2 = r1 - mid;
-            memcpy(&bits, &r2, 4);
-            e_hi[at] = (uint16_t)(hb >> 16);
-            e_mid[at] = (uint16_t)(mb >> 16);
-            e_lo[at] = (uint16_t)(bits >> 16);
-        };
-        auto entry = [&](int off, int index) { return reinterpret_cast<uint16_t*>(blob + off + (size_t)index * kSplitEntry); };
-        for (int g = 0; g < 3; ++g)
-            for (int mt = 0; mt < UT; ++mt)
+    // float16 tables: weights times the largest power of two that keeps every one of them under float16's 65504
+    // (rnn_device.h).  Sw may be negative for outsized weights; 13 already places |w| >= 2^-14 on the exact side.
+    double wmax = 0.0;
+    for (int g = 0; g < G; ++g)
+        for (int i = 0; i < H * H; ++i) wmax = fmax(wmax, fabs(gate_scale(g) * (double)w_hh[(size_t)g * H * H + i]));
+    for (int i = 0; i < rows * kT * H; ++i) wmax = fmax(wmax, fabs((double)hw[i]));
+    int sw = 13;
+    while (sw > -100 && ldexp(wmax, sw) > 65000.0) --sw;
+    VAD_REQUIRE(wmax - wmax == 0.0 && sw > -100, "weights are not finite");
+    const float wscale = ldexpf(1.0f, sw);
+    tail[kTailScale(large != 0) + 0] = ldexpf(1.0f, kStateShift + sw);
+    tail[kTailScale(large != 0) + 1] = ldexpf(1.0f, -(kStateShift + sw));
+    tail[kTailScale(large != 0) + 2] = wscale;
+    bool f16_finite = true;
+    for (int fmt = 0; fmt < 2; ++fmt) {
+        const bool f16 = fmt == 1;
+        const float ws = f16 ? wscale : 1.0f;
+        const int off_hh = f16 ? L.h_hh : L.s_hh, off_head = f16 ? L.h_head : L.s_head;
+        if (UT == 1) {
+            // (hi, mid, lo) images of the float32 A operands above as v_mfma_f32_16x16x32_{bf16,f16} A operands: sub-tile
+            // mi, lane l = 16 q + m holds tile row 16 mi + m, k-slots 8 q + j = tile rows split_row_of_k_slot(q, j); in the
+            // float32 image tile row p is k-step (p & 3) + 4 (p >> 3) of lane half (p >> 2) & 1
+            auto split_tile = [&](const float* a16, float* dst) {      // a16: [16][64] floats -> [2][3][64][8 x 16 bit]
+                uint16_t* out = reinterpret_cast<uint16_t*>(dst);
+                for (int mi = 0; mi < 2; ++mi)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int m = 16 * mi + (lane & 15), p = split_row_of_k_slot(lane >> 4, j);
+                            uint16_t t3[3];
+                            split3_host(ws * a16[((p & 3) + 4 * (p >> 3)) * 64 + m + 32 * ((p >> 2) & 1)], f16, t3, &f16_finite);
+                            for (int term = 0; term < 3; ++term) out[(((mi * 3 + term) * 64 + lane) * 8) + j] = t3[term];
+                        }
+            };
+            for (int g = 0; g < G; ++g) split_tile(blob + L.a_hh + g * kHk * 64, blob + off_hh + g * kSplitTile);
+            for (int t = 0; t < kT; ++t) split_tile(blob + L.head + t * kHk * 64, blob + off_head + t * kSplitTile);
+        } else {
+            // wide GRU.  Entry (rows 16 mi .. + 15 of unit tile mt, k-block kb): lane l = 16 q + m holds tile row 16 mi + m
+            // of tile mt and, as k-slots 8 q + j, the tile rows split_row_of_k_slot(q, j) of tile kb (rnn_device.h); rows
+            // and slots that carry no unit stay zero.
+            auto entry = [&](int off, int index) { return reinterpret_cast<uint16_t*>(blob + off + (size_t)index * kSplitEntry); };
+            auto put = [&](float x, uint16_t* e_hi, uint16_t* e_mid, uint16_t* e_lo, int at) {
+                uint16_t t3[3];
+                split3_host(ws * x, f16, t3, &f16_finite);
+                e_hi[at] = t3[0];
+                e_mid[at] = t3[1];
+                e_lo[at] = t3[2];
+            };
+            for (int g = 0; g < 3; ++g)
+                for (int mt = 0; mt < UT; ++mt)
+                    for (int mi = 0; mi < 2; ++mi)
+                        for (int kb = 0; kb < UT; ++kb) {
+                            const int base = wide_split_base(UT, g, mt, mi, kb);
+                            uint16_t* e_hi = entry(off_hh, base * 2 + 0);
+                            uint16_t* e_mid = entry(off_hh, base * 2 + 1);
+                            uint16_t* e_lo = entry(off_hh, wide_split_hm_entries(UT) + base);
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int m = unit_at(mt, 16 * mi + (lane & 15));
+                                    const int u = unit_at(kb, split_row_of_k_slot(lane >> 4, j));
+                                    const float x = (m < 0 || u < 0) ? 0.0f : (float)(gate_scale(g) * (double)w_hh[(g * H + m) * H + u]);
+                                    put(x, e_hi, e_mid, e_lo, lane * 8 + j);
+                                }
+                        }
+            for (int t = 0; t < kT; ++t)
                 for (int mi = 0; mi < 2; ++mi)
                     for (int kb = 0; kb < UT; ++kb) {
-                        const int base = wide_split_base(UT, g, mt, mi, kb);
-                        uint16_t* e_hi = entry(L.s_hh, base * 2 + 0);
-                        uint16_t* e_mid = entry(L.s_hh, base * 2 + 1);
-                        uint16_t* e_lo = entry(L.s_hh, wide_split_hm_entries(UT) + base);
+                        const int base = ((t * 2 + mi) * UT + kb) * 3;
+                        uint16_t* e_hi = entry(off_head, base + 0);
+                        uint16_t* e_mid = entry(off_head, base + 1);
+                        uint16_t* e_lo = entry(off_head, base + 2);
                         for (int lane = 0; lane < 64; ++lane)
                             for (int j = 0; j < 8; ++j) {
-                                const int m = unit_at(mt, 16 * mi + (lane & 15));
+                                const int o = 16 * mi + (lane & 15);
                                 const int u = unit_at(kb, split_row_of_k_slot(lane >> 4, j));
-                                const float x = (m < 0 || u < 0) ? 0.0f : (float)(gate_scale(g) * (double)w_hh[(g * H + m) * H + u]);
+                                const float x = (o < rows && u >= 0) ? hw[o * (kT * H) + t * H + u] : 0.0f;
                                 put(x, e_hi, e_mid, e_lo, lane * 8 + j);
                             }
                     }
-        for (int t = 0; t < kT; ++t)
-            for (int mi = 0; mi < 2; ++mi)
-                for (int kb = 0; kb < UT; ++kb) {
-                    const int base = ((t * 2 + mi) * UT + kb) * 3;
-                    uint16_t* e_hi = entry(L.s_head, base + 0);
-                    uint16_t* e_mid = entry(L.s_head, base + 1);
-                    uint16_t* e_lo = entry(L.s_head, base + 2);
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int o = 16 * mi + (lane & 15);
-                            const int u = unit_at(kb, split_row_of_k_slot(lane >> 4, j));
-                            const float x = (o < rows && u >= 0) ? hw[o * (kT * H) + t * H + u] : 0.0f;
-                            put(x, e_hi, e_mid, e_lo, lane * 8 + j);
-                        }
-                }
+        }
     }
+    VAD_REQUIRE(f16_finite, "a weight does not fit the float16 tables");     // cannot happen: wscale was chosen for it
     return VAD_OK;
 }
 

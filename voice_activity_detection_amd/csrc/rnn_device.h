@@ -28,14 +28,21 @@ struct NetLayout {
     int a_hh;         // [gates][ut][ut*16][64]     A operands of the recurrent product
     int cb;           // [4][ut][2][16]             accumulator initial values (biases), per lane half
     int head;         // a1 [30][ut*16][64]         A operands of lin1 (large) or lin (small, rows 0-1)
-    int tail;         // large: b1e [2][16], w2e [2][2][16], b2 [2] (+2 pad); small: bl [2] (+2 pad)
+    int tail;         // large: b1e [2][16], w2e [2][2][16], b2 [2], 2 pad; small: bl [2], 2 pad; then for the float16 tables
+                      // 2^S, 2^-S, 2^Sw, pad (kTailScale: S = kStateShift + Sw, the accumulators' scale; see split_f16)
     int s_hh;         // ut == 1: [gates][2][3][64] x 8 bf16   a_hh split into bf16 (hi, mid, lo) A operands;
                       // ut > 1 (GRU): wide_split_gate_entries(ut) entries of [64] x 8 bf16, order above
     int s_head;       // ut == 1: [30][2][3][64] x 8 bf16      the head's A operands, split the same way;
                       // ut > 1: [30][2 mi][ut kb][3 terms][64] x 8 bf16
+    int h_hh;         // the same two tables with the operands split into three float16 (split_f16 below)
+    int h_head;
     int total;
 };
 
+__host__ __device__ constexpr int kTailScale(bool large) { return large ? 2 * 16 + 2 * 2 * 16 + 4 : 4; }   // floats of the tail before the scales
+constexpr int kStateShift = 14;              // float16 modes keep the hidden state as 2^14 h
+constexpr float kStateScale = 16384.0f;      // 2^kStateShift
+constexpr float kStateUnscale = 1.0f / 16384.0f;
 constexpr int kSplitTile = 2 * 3 * 64 * 4;   // dwords of one split 32x32 A tile: 2 halves of 16 rows, 3 terms, 16 B per lane
 constexpr int kSplitEntry = 64 * 4;          // dwords of one bf16 A operand of v_mfma_f32_16x16x32_bf16 (16 rows x 32 k)
 
@@ -62,9 +69,13 @@ __host__ __device__ inline NetLayout net_layout(bool lstm, bool large, int ut = 
     L.cb = L.a_hh + L.gates * ut * ut * kHk * 64;
     L.head = L.cb + 4 * ut * 2 * 16;
     L.tail = L.head + kT * ut * kHk * 64;
-    L.s_hh = L.tail + (large ? (2 * 16 + 2 * 2 * 16 + 4) : 4);
-    L.s_head = L.s_hh + (ut == 1 ? L.gates * kSplitTile : wide_split_gate_entries(ut) * kSplitEntry);
-    L.total = L.s_head + (ut == 1 ? kT * kSplitTile : kT * 2 * ut * 3 * kSplitEntry);
+    L.s_hh = L.tail + kTailScale(large) + 4;
+    const int hh_floats = ut == 1 ? L.gates * kSplitTile : wide_split_gate_entries(ut) * kSplitEntry;
+    const int head_floats = ut == 1 ? kT * kSplitTile : kT * 2 * ut * 3 * kSplitEntry;
+    L.s_head = L.s_hh + hh_floats;
+    L.h_hh = L.s_head + head_floats;
+    L.h_head = L.h_hh + hh_floats;
+    L.total = L.h_head + head_floats;
     return L;
 }
 
@@ -132,6 +143,80 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 #define MFMA_BF16(a, b, c) \
     __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
+// ---- the same on float16 operands ---------------------------------------------------------------------
+// float16 carries 11 significant bits against bfloat16's 8, so three terms overshoot float32's 24 bits and six
+// partial products reach what nine bfloat16 ones do: with x = hi + mid + lo split by round-to-nearest
+// (hi = f16(x), mid = f16(x - hi), lo = f16(x - hi - mid); |mid| <= 2^-12 |x|, |lo| <= 2^-24 |x|) the products left
+// out of the six -- mid * lo, lo * mid, lo * lo -- are below 2^-35 of x * y.  float16's narrow exponent is dealt with
+// by powers of two, which cost no rounding: three terms are exact while the last bit of x is at least 2^-24
+// (float16's smallest subnormal), i.e. for 0.5 <= |x| <= 65504, so the hidden state is carried as H = 2^14 h
+// (|h| <= 1: exact from |h| = 2^-15 up, and rounded to a 2^-39 grid below) and the packer multiplies the weights
+// by the largest 2^Sw that keeps them under 65504.  The accumulators then hold 2^S times the pre-activations,
+// S = 14 + Sw: the projected rows and biases they start from are multiplied by 2^S, and the gate math multiplies
+// by 2^-S before its exponentials -- two vector multiplies per GRU unit and step, four per LSTM unit; everywhere
+// else the power of two rides in a constant of an existing fused multiply-add.  'f16x4' keeps hi * hi, hi * mid,
+// mid * hi, mid * mid of the same split: products to 2^-23, four instructions.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+#define MFMA_F16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+
+template <bool F16>
+__device__ __forceinline__ f32x4s mfma_split(const u32x4& a, const u32x4& b, const f32x4s& c) {
+    if (F16) return MFMA_F16(a, b, c);
+    return MFMA_BF16(a, b, c);
+}
+
+// (x0, x1) -> one dword per term, x0 in the low half.  `lo` is only formed when WITH_LO.
+struct SplitTerms {
+    unsigned hi, mid, lo;
+};
+
+template <bool F16, bool WITH_LO>
+__device__ __forceinline__ SplitTerms split_pair(float x0, float x1) {
+    unsigned hi, mid, lo = 0;
+    if (F16) {
+        // x - (float)f16(x) is exact
+#if defined(VAD_F16_SPLIT_PLAIN)
+        const f16x2 h = __builtin_convertvector(f32x2s{x0, x1}, f16x2);
+        const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+        const f16x2 m = __builtin_convertvector(f32x2s{r0, r1}, f16x2);
+        hi = __builtin_bit_cast(unsigned, h);
+        mid = __builtin_bit_cast(unsigned, m);
+        if (WITH_LO) {
+            const float q0 = r0 - (float)m[0], q1 = r1 - (float)m[1];
+            lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{q0, q1}, f16x2));
+        }
+#else
+        // the residuals by v_fma_mix_f32: a float32 fma whose first operand is read as the low / high float16 of a dword
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{x0, x1}, f16x2));
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(x1));
+        mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{r0, r1}, f16x2));
+        if (WITH_LO) {
+            float q0, q1;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(mid), "v"(r0));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(mid), "v"(r1));
+            lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{q0, q1}, f16x2));
+        }
+#endif
+    } else {
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
+        const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
+        // upper halves of (second, first) -> one dword, first in the low half
+        hi = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+        mid = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+        if (WITH_LO) {
+            const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
+            const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+            lo = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+        }
+    }
+    return SplitTerms{hi, mid, lo};
+}
+
 __host__ __device__ inline int split_index(int mi, int ni, int i) { return (2 * mi + ni) * 4 + i; }
 __host__ __device__ inline int split_row_of_k_slot(int q, int j) { return 16 * (j >> 2) + 4 * q + (j & 3); }
 
@@ -140,33 +225,30 @@ struct SplitB {
     u32x4 hi[2], mid[2], lo[2];
 };
 
-template <int NI = 2>
+template <int NI = 2, bool F16 = false, bool WITH_LO = true>
 __device__ __forceinline__ void split_state(SplitB& b, const f32x16& h) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
             const int j = 2 * jp;                                       // j and j + 1 share j >> 2
-            const float x0 = h[split_index(j >> 2, ni, j & 3)], x1 = h[split_index(j >> 2, ni, (j & 3) + 1)];
-            const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
-            const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
-            const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xFFFF0000u);
-            const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-            // upper halves of (second, first) -> one dword, first in the low half
-            b.hi[ni][jp] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-            b.mid[ni][jp] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
-            b.lo[ni][jp] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+            const SplitTerms s = split_pair<F16, WITH_LO>(h[split_index(j >> 2, ni, j & 3)], h[split_index(j >> 2, ni, (j & 3) + 1)]);
+            b.hi[ni][jp] = s.hi;
+            b.mid[ni][jp] = s.mid;
+            b.lo[ni][jp] = s.lo;
         }
 }
 
 // acc += A . B for one split 32 x 32 tile; `a` points at the tile's [2 mi][3 terms][64 lanes] 16-byte entries
 // (LDS or global memory)
-template <int TERMS, int NI = 2>
+template <int TERMS, int NI = 2, bool F16 = false>
 __device__ __forceinline__ f32x16 split_tile_mfma(f32x16 acc, const u32x4* a, const SplitB& b, int lane) {
-    static_assert(TERMS == 6 || TERMS == 8 || TERMS == 9, "6, 8 or 9 partial products");
+    static_assert(TERMS == 4 || TERMS == 6 || TERMS == 8 || TERMS == 9, "4, 6, 8 or 9 partial products");
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        const u32x4 ah = a[(mi * 3 + 0) * 64 + lane], am = a[(mi * 3 + 1) * 64 + lane], al = a[(mi * 3 + 2) * 64 + lane];
+        const u32x4 ah = a[(mi * 3 + 0) * 64 + lane], am = a[(mi * 3 + 1) * 64 + lane];
+        u32x4 al = ah;
+        if (TERMS > 4) al = a[(mi * 3 + 2) * 64 + lane];
         f32x4s c[NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
@@ -174,15 +256,17 @@ __device__ __forceinline__ f32x16 split_tile_mfma(f32x16 acc, const u32x4* a, co
             for (int i = 0; i < 4; ++i) c[ni][i] = acc[split_index(mi, ni, i)];
         auto term = [&](const u32x4& at, const u32x4 (&bt)[2]) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) c[ni] = MFMA_BF16(at, bt[ni], c[ni]);
+            for (int ni = 0; ni < NI; ++ni) c[ni] = mfma_split<F16>(at, bt[ni], c[ni]);
         };
         if (TERMS == 9) term(al, b.lo);                     // smallest terms first
         if (TERMS >= 8) {
             term(am, b.lo);
             term(al, b.mid);
         }
-        term(ah, b.lo);
-        term(al, b.hi);
+        if (TERMS >= 6) {
+            term(ah, b.lo);
+            term(al, b.hi);
+        }
         term(am, b.mid);
         term(ah, b.mid);
         term(am, b.hi);
@@ -242,6 +326,48 @@ __device__ __forceinline__ void gate_update(const f32x16 (&acc)[4], f32x16& h, f
             const float r = sigmoid_pre(acc[0][i]);
             const float z = sigmoid_pre(acc[1][i]);
             const float n = tanh_pre(fmaf(r, acc[3][i], acc[2][i]));
+            h[i] = fmaf(z, h[i] - n, n);
+        }
+    }
+}
+
+// The same for the float16 modes: the accumulators hold 2^S times the pre-activations (`up` = 2^S, `inv` = 2^-S) --
+// except the GRU's n-input part acc[2], which no matrix product touches -- and the state is H = 2^14 h.
+// a[i] * s for the 16 elements of a tile
+__device__ __forceinline__ f32x16 scale16(const f32x16& a, float s) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = a[i] * s;
+    return r;
+}
+
+template <bool LSTM, int NI = 2>
+__device__ __forceinline__ void gate_update_scaled(const f32x16 (&acc_in)[4], f32x16& h, f32x16& c, float up, float inv) {
+    // back to the pre-activations' own scale, except the GRU's hidden n part, whose 2^-S rides on r
+    f32x16 acc[4];
+    acc[0] = scale16(acc_in[0], inv);
+    acc[1] = scale16(acc_in[1], inv);
+    acc[2] = LSTM ? scale16(acc_in[2], inv) : acc_in[2];
+    acc[3] = LSTM ? scale16(acc_in[3], inv) : acc_in[3];
+    inv = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (NI == 1 && ((i >> 2) & 1)) continue;
+        if (LSTM) {
+            const float ig = sigmoid_pre(acc[0][i] * inv);
+            const float fg = sigmoid_pre(acc[1][i] * inv);
+            const float gg = tanh_pre(acc[2][i] * inv);
+            const float og = sigmoid_pre(acc[3][i] * inv);
+            const float cn = fmaf(fg, c[i], ig * gg);
+            c[i] = cn;
+            // 2^14 tanh(c)
+            h[i] = og * fmaf(-2.0f * kStateScale, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * cn)),
+                             kStateScale);
+        } else {
+            const float r_inv = __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(acc[0][i] * inv), up, up));   // 2^-S r
+            const float z = sigmoid_pre(acc[1][i] * inv);
+            const float n = fmaf(-2.0f * kStateScale,
+                                 __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(r_inv, acc[3][i], acc[2][i]))), kStateScale);
             h[i] = fmaf(z, h[i] - n, n);
         }
     }
@@ -372,10 +498,11 @@ __device__ __forceinline__ float sum_over_q(float x) {          // over the four
 
 // (ReLU, lin2) or the bias of lin; softmax over the 2 classes; decision.  Window half ni of lane 16 q + n is
 // window w_first + 16 ni; the lanes with q = 0 store.
+// `unscale`: what the head's sums are multiplied by (1, or the power of two the float16 modes carry in them).
 template <bool LARGE, int NI = 2>
 __device__ __forceinline__ void split_head_epilogue(const f32x16& lacc, const float* __restrict__ tail, int lane, long w_first,
                                                     long n_windows, float* __restrict__ p_out, uint8_t* __restrict__ dec_out,
-                                                    int mode, float threshold) {
+                                                    int mode, float threshold, float unscale = 1.0f) {
     const int q = lane >> 4;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -387,15 +514,15 @@ __device__ __forceinline__ void split_head_epilogue(const f32x16& lacc, const fl
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int e = split_image_elem(q, mi) + i;
-                    const float v = fmaxf(lacc[split_index(mi, ni, i)] + tail[hh * 16 + e], 0.0f);
+                    const float v = fmaxf(fmaf(lacc[split_index(mi, ni, i)], unscale, tail[hh * 16 + e]), 0.0f);
                     l0 = fmaf(v, tail[32 + (0 * 2 + hh) * 16 + e], l0);
                     l1 = fmaf(v, tail[32 + (1 * 2 + hh) * 16 + e], l1);
                 }
             l0 = sum_over_q(l0) + tail[96];
             l1 = sum_over_q(l1) + tail[97];
         } else {
-            l0 = sum_over_q(lacc[2 * ni]) + tail[0];
-            l1 = sum_over_q(lacc[2 * ni + 1]) + tail[1];
+            l0 = fmaf(sum_over_q(lacc[2 * ni]), unscale, tail[0]);
+            l1 = fmaf(sum_over_q(lacc[2 * ni + 1]), unscale, tail[1]);
         }
         const float m = fmaxf(l0, l1);
         const float e0 = expf(l0 - m), e1 = expf(l1 - m);

@@ -19,7 +19,7 @@ from .common import BATCH_SIZE, FEATURES, FRAMES
 
 DECIDE_ARGMAX = 0
 DECIDE_THRESHOLD = 1
-MATRIX_MODES = {'f32': 0, 'bf16x6': 1, 'bf16x9': 2, 'bf16x8': 3}
+MATRIX_MODES = {'f32': 0, 'bf16x6': 1, 'bf16x9': 2, 'bf16x8': 3, 'f16x6': 4, 'f16x4': 5}
 
 
 def set_matrix_mode(mode):
@@ -27,9 +27,12 @@ def set_matrix_mode(mode):
     model / per call): how the stride-1 GRU / LSTM kernels (and the wide GRU's stride-1 workspace path) form their
     float32 matrix products.
     'bf16x9' splits every float32 operand exactly into three bfloat16 and accumulates all nine exact partial
-    products in float32 on the bf16 matrix pipe; 'bf16x8' (default) leaves out the lo * lo product, under 2^-30
+    products in float32 on the bf16 matrix pipe; 'bf16x8' leaves out the lo * lo product, under 2^-30
     of the product it belongs to; 'f32' is the float32 MFMA (a k-ordered FMA chain, bit-identical to the
     dense-batch and sampled-window paths); 'bf16x6' drops the three smallest partial products (up to 2^-23).
+    'f16x6' (default) does the same with three float16 terms per operand (11 significant bits each): six partial products
+    leave out under 2^-35 of a product; the state and the weights ride on exact power-of-two scales that keep them
+    inside float16's exponent range.  'f16x4' keeps four of the products (to 2^-23).
     Returns the previous mode's name."""
     L = _lib.lib()
     if mode not in MATRIX_MODES:
@@ -84,7 +87,7 @@ class _HipModule(nn.Module):
         argmax (core/train.py:605-607) or ``p[:,1] >= threshold``
         (core/train.py:486-487).
 
-        ``matrix_mode``  'f32', 'bf16x9', 'bf16x8' or 'bf16x6' for this call (GRU / LSTM over stride-1
+        ``matrix_mode``  'f32', 'f16x6', 'f16x4', 'bf16x9', 'bf16x8' or 'bf16x6' for this call (GRU / LSTM over stride-1
                windows; see ``set_matrix_mode``).  None: the module's ``matrix_mode`` attribute, and if
                that is None too, the process-wide mode.
         ``workspace``    uint8 CUDA tensor for the stride-1 scratch of GRUs with more than 32 units
