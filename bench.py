@@ -305,7 +305,10 @@ def compact_record(out):
     No notes, no per-kernel duplicates; every string stays short."""
     def roof(k):
         keep = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes', 'ms_per_launch')
-        return {key: _r(k.get(key)) for key in keep}
+        r = {key: _r(k.get(key)) for key in keep}
+        if 'fp32_frac' in k:        # the front end is vector-ALU bound: its fraction of the fp32 peak is the binding one
+            r['frac_fp32'] = _r(k['fp32_frac'])
+        return r
 
     c = {key: _r(out[key]) for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
                                        'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'dtype_note', 'matrix_mode',

@@ -47,7 +47,7 @@ using rnn::tanh_pre;
 constexpr int kT = VAD_FRAMES;
 constexpr int kF = VAD_FEATURES;
 constexpr int kWaveWindows = 16;
-constexpr int kWaves = 8;                  // per block: two per SIMD
+constexpr int kWaves = 8;                  // per block: two per SIMD (4 waves: +6 % time, 12: no change)
 constexpr int kXk = kF / 4;                // k-steps of the feature rows: lane group q supplies feature 6 q + s
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -138,6 +138,10 @@ __host__ __device__ constexpr NnLayout nn_layout() {
 struct Tile {
     f32x4 b[2];
 };
+
+// Between the pipeline's stages: left free, the scheduler starts the next stage's operand reads (24 registers per
+// group of k-steps) under the current one, which costs the large model registers it does not have.
+#define NN_STAGE_FENCE __builtin_amdgcn_sched_barrier(0)
 
 template <int NU>
 __device__ __forceinline__ void tile_kvals(const Tile& t, float (&v)[tile_ksteps(NU)]) {
@@ -392,9 +396,13 @@ __global__ __launch_bounds__(kWaves * 64) void nicknet_kernel(const float* __res
                 }
                 // conv layer l is at position p - l and reads layer l - 1 at p - l - 1, p - l, p - l + 1: the ring of
                 // layer l - 1 after this iteration's shift
+                NN_STAGE_FENCE;
                 conv_stage<LARGE, 1>(ring[0], cur, p, a_lane, lds, q);
+                NN_STAGE_FENCE;
                 conv_stage<LARGE, 2>(ring[1], cur, p, a_lane, lds, q);
+                NN_STAGE_FENCE;
                 if constexpr (NC > 3) conv_stage<LARGE, 3>(ring[2], cur, p, a_lane, lds, q);
+                NN_STAGE_FENCE;
             } else if (t >= 0) {                                 // the trunk's output is given: (B, C, 30)
 #pragma unroll
                 for (int blk = 0; blk < n_blocks(C); ++blk)
@@ -414,11 +422,13 @@ __global__ __launch_bounds__(kWaves * 64) void nicknet_kernel(const float* __res
                         if (c < C) so.trunk[(w * C + c) * kT + t] = cur.b[blk][i];
                     }
             }
+            NN_STAGE_FENCE;
             {
                 float xin[tile_ksteps(C)];
                 tile_kvals<C>(cur, xin);
                 gru_step<LARGE, 0>(h[0], xin, a_lane, lds, t == 0, q);
             }
+            NN_STAGE_FENCE;
             if constexpr (D::layers > 1) {
                 float xin[tile_ksteps(H)];
                 tile_kvals<H>(h[0], xin);
