@@ -176,15 +176,20 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
                 // (fetching the wave's next frame under the FFT instead was measured slower, with and without
                 // register spills: 18.3 -> 18.8 ms per 100 h at 130 registers)
                 RawFrame raw;
+                FE_STAMP(0);
                 frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
                 if (it > 0) filter_sums(parts, en + (it - 1) * 32, K);      // the previous frame's, under this load
                 frame_energies(raw, tws, off512, K, ex, parts);
+                FE_STAMP(9);
+                if (it + 1 < kFramesPerWave && j + 1 < last) FE_NEXT_FRAME();
             }
             filter_sums(parts, en + (nfr - 1) * 32, K);
             wave_lds_fence();
+            FE_STAMP(10);
             const int tl = fresh_lane();                                    // see fresh_lane: nothing of the tail's
             cepstra_tail(en, reinterpret_cast<double*>(wbase), dctb, nfr, tl, ring, (fbase - first) % kRingRows, 1,
                          kRingRows);                                        // addressing stays live over the frames
+            FE_STAMP(11);
             // MFCC rows [first, avail) are in the ring; a row can be written once the rows its delta reads are:
             // everything owned in the last round, otherwise up to two rows behind.
             const int avail = last - fbase > kFramesPerWave ? fbase + kFramesPerWave : last;
@@ -193,6 +198,8 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
             emit_rows(ring, first, n, emitted, n_emit, tl, mfcc, mfcc_ld, delta, delta_ld);
             emitted += n_emit;
             wave_lds_fence();                                               // ring reads before the next round's writes
+            FE_STAMP(12);
+            FE_NEXT_FRAME();
         }
     }
 }
@@ -386,3 +393,13 @@ extern "C" int vad_mfcc_delta_slices_f32(const int16_t* frames_dev, const int64_
     return launch_mfcc(frames_dev, m, (long)n_slices, (long)max_slice_frames, mfcc_dev, (long)mfcc_ld, delta_dev,
                        (long)delta_ld, reinterpret_cast<hipStream_t>(stream));
 }
+
+#if defined(VAD_FE_TIMELINE)
+extern "C" int vad_debug_fe_timeline(unsigned long long* out_host) {
+    VAD_HIP_CHECK(hipDeviceSynchronize());
+    VAD_HIP_CHECK(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(vad::fe::g_fe_timeline), sizeof(vad::fe::g_fe_timeline)));
+    const int zero = 0;
+    VAD_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(vad::fe::g_fe_tl_frame), &zero, sizeof(int)));
+    return vad::fe::kFeTlFrames * vad::fe::kFeTlStamps;
+}
+#endif

@@ -61,6 +61,28 @@ static_assert(offsetof(MfccTables, pow_off) % 16 == 0 && offsetof(MfccTables, dc
 // ---------------------------------------------------------------------------------------------
 // device helpers
 
+// Diagnostic build only (-DVAD_FE_TIMELINE=<block>): s_memtime stamps of wave 0 of one block at the stage boundaries
+// of its first frames, read back through vad_debug_fe_timeline (tools/timeline_fe.py).  A stamp waits for the
+// wave's outstanding LDS and scalar operations, so the stages it separates do not overlap as they do in the product.
+#if defined(VAD_FE_TIMELINE)
+constexpr int kFeTlFrames = 96, kFeTlStamps = 16;
+__device__ unsigned long long g_fe_timeline[kFeTlFrames][kFeTlStamps];
+__device__ int g_fe_tl_frame;
+#define FE_STAMP(k)                                                                                           \
+    do {                                                                                                      \
+        const unsigned long long fe_now = __builtin_amdgcn_s_memtime();                                       \
+        if (blockIdx.x == VAD_FE_TIMELINE && threadIdx.x == 0 && g_fe_tl_frame < kFeTlFrames)                 \
+            g_fe_timeline[g_fe_tl_frame][k] = fe_now;                                                         \
+    } while (0)
+#define FE_NEXT_FRAME()                                                                                       \
+    do {                                                                                                      \
+        if (blockIdx.x == VAD_FE_TIMELINE && threadIdx.x == 0) g_fe_tl_frame = g_fe_tl_frame + 1;             \
+    } while (0)
+#else
+#define FE_STAMP(k)
+#define FE_NEXT_FRAME()
+#endif
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -221,6 +243,10 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         v[jj] = make_float2(x0, x1);
     }
     v[15] = make_float2(0.0f, 0.0f);                        // samples 1920..2047 are zero padding
+#if defined(VAD_FE_TIMELINE)
+    asm volatile("" : "+v"(v[0].x), "+v"(v[14].y));          // the samples have arrived
+#endif
+    FE_STAMP(1);
 
     // ---- pass A: radix 16 over jj in registers; register k1 then holds sub-transform k1 of point n2 = lane;
     //      twiddle W1024^(n2 k1) ----
@@ -232,12 +258,14 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) ex[k1 * kExStride + lane] = v[k1];
     wave_lds_fence();
+    FE_STAMP(2);
     {
         const float2* rd = ex + k1l * kExStride + al;
 #pragma unroll
         for (int b = 0; b < 16; ++b) v[b] = rd[4 * b];
     }
     wave_lds_fence();
+    FE_STAMP(3);
 
     // ---- pass B: radix 16 over b -> q; twiddle W64^(a q), with the signs pass C expects (tw2) ----
     dft16(v);
@@ -247,6 +275,10 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     }
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], K.tw2[k - 1]);
+#if defined(VAD_FE_TIMELINE)
+    asm volatile("" : "+v"(v[1].x), "+v"(v[15].y));
+#endif
+    FE_STAMP(4);
 
     // ---- pass C: radix 4 over a, across the four lanes of a quad (DPP operands, no LDS).  With x_a the
     //      twiddled values (lanes 1..3 hold them negated):
@@ -290,6 +322,7 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         }
 #undef VAD_QUAD_FMAC8
     }
+    FE_STAMP(5);
 
     // ---- real-input untangle on the pairs (k, 1024 - k) (fft_bin: which pair a lane takes in step u):
     //      with a = Z[k], b = Z[1024 - k], E = a + conj(b), O = a - conj(b), T = W2048^k O,
@@ -316,6 +349,7 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         partner[u].y = __int_as_float(__builtin_amdgcn_ds_bpermute(u ? paddr : paddr0, __float_as_int(send.y)));
     }
     __builtin_amdgcn_sched_barrier(0);
+    FE_STAMP(6);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         float2 a = v[jj];
@@ -336,6 +370,7 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     if (lane == 1)                                                                             // the self-paired bin 512
         *reinterpret_cast<float*>(pwb + off512) = (v[0].x * v[0].x + v[0].y * v[0].y) * 4.0f;
     wave_lds_fence();
+    FE_STAMP(7);
 
     // ---- mel segments: each lane sums a run of <= 20 bins of one segment (no branches: the lane reads
     // its whole 20-float slot in five 16-byte reads, elements past its run count as zeros) ----
@@ -346,15 +381,31 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         f32x4v piece[kRunSlot / 4];
 #pragma unroll
         for (int q = 0; q < kRunSlot / 4; ++q) piece[q] = run4[q];
+#if defined(VAD_MEL_PER_BIN)
 #pragma unroll
         for (int i = 0; i < kMaxRun; ++i) {
             const float p = (i < K.run_count) ? piece[i >> 2][i & 3] : 0.0f;
             sr = fmaf(p, fmaf((float)i, K.run_inv, K.run_w0), sr);
             sf = fmaf(p, fmaf(-(float)i, K.run_inv, K.run_f0), sf);
         }
+#else
+        // The weights of a run are affine in the bin's position i: rising w0 + i inv, falling f0 - i inv.  Two plain
+        // sums over the run, S0 = sum p_i and S1 = sum i p_i (all terms non-negative), then
+        // rising = w0 S0 + inv S1, falling = f0 S0 - inv S1: three vector instructions per bin instead of five.
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kMaxRun; ++i) {
+            const float p = (i < K.run_count) ? piece[i >> 2][i & 3] : 0.0f;
+            s0 += p;
+            if (i) s1 = fmaf((float)i, p, s1);
+        }
+        sr = fmaf(K.run_inv, s1, K.run_w0 * s0);
+        sf = fmaf(-K.run_inv, s1, K.run_f0 * s0);
+#endif
         parts[lane] = sr;
         parts[64 + lane] = sf;
     }
+    FE_STAMP(8);
 }
 
 // filter f = rising parts of segment f + falling parts of segment f+1, in a fixed order; en_slot[0..25].
