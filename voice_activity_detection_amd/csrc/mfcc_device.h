@@ -381,14 +381,6 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         f32x4v piece[kRunSlot / 4];
 #pragma unroll
         for (int q = 0; q < kRunSlot / 4; ++q) piece[q] = run4[q];
-#if defined(VAD_MEL_PER_BIN)
-#pragma unroll
-        for (int i = 0; i < kMaxRun; ++i) {
-            const float p = (i < K.run_count) ? piece[i >> 2][i & 3] : 0.0f;
-            sr = fmaf(p, fmaf((float)i, K.run_inv, K.run_w0), sr);
-            sf = fmaf(p, fmaf(-(float)i, K.run_inv, K.run_f0), sf);
-        }
-#else
         // The weights of a run are affine in the bin's position i: rising w0 + i inv, falling f0 - i inv.  Two plain
         // sums over the run, S0 = sum p_i and S1 = sum i p_i (all terms non-negative), then
         // rising = w0 S0 + inv S1, falling = f0 S0 - inv S1: three vector instructions per bin instead of five.
@@ -401,7 +393,6 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
         }
         sr = fmaf(K.run_inv, s1, K.run_w0 * s0);
         sf = fmaf(-K.run_inv, s1, K.run_f0 * s0);
-#endif
         parts[lane] = sr;
         parts[64 + lane] = sf;
     }
