@@ -291,11 +291,6 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
     // share a SIMD (w and w + 4) overlap while they are in different phases. ----
     constexpr int NI = C::ni;
     if (w0 + wave * C::wave_windows >= n_windows) return;       // wave-uniform, after the only barrier
-#if defined(VAD_PRIO_SPLIT)
-    if (VAD_PRIO_SPLIT == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    if (VAD_PRIO_SPLIT == 2 && wave < 4) __builtin_amdgcn_s_setprio(1);
-    if (VAD_PRIO_SPLIT == 3) { if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2); }
-#endif
     const int q = lane >> 4, n = lane & 15;
     const long w_first = w0 + wave * C::wave_windows + n;        // the lane's windows: w_first (and w_first + 16)
     const float* a1 = blob + L.head;
@@ -308,7 +303,12 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
     const float* cb_n = cb + (3 * 2 + split_image_half(q)) * 16;             // b_hn of the lane's rows
     SplitB b;
 
-    for (int t = 0; t < kT; ++t) {
+    // One step.  kind 1: the first step (no recurrent product: the state is zero), 0: a later one, 2: either, decided by t.
+    // The float16 GRU peels the first step off the loop, so that its loop body has no branch around the matrix work and
+    // the accumulators are not merges of two paths (GRU-large 15.9 -> 15.3 ms per 100 h, GRU-small 15.4 -> 14.1); the
+    // LSTM and the bfloat16 forms gain nothing from it or lose (GRU-large bf16x8 16.6 -> 17.6 ms) and keep the branch.
+    auto step = [&](auto kind, const int t) __attribute__((always_inline)) {
+        const bool with_product = decltype(kind)::value == 2 ? t > 0 : decltype(kind)::value == 0;
         SplitHeadWeights hw;                                     // 2-row head: vector ALU, float32 weights
         if (!LARGE) split_head_load(hw, a1, t, lane);
         f32x16 acc[4];
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
                 }
             }
         }
-        if (t > 0) {                                             // b holds the split of h_{t-1}
+        if (with_product) {                                      // b holds the split of h_{t-1}
             if (LARGE) lacc = split_tile_mfma<TERMS, NI, F16>(lacc, s_head + (t - 1) * (kSplitTile / 4), b, lane);
             if (LSTM) {
 #pragma unroll
@@ -352,6 +352,12 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
         else gate_update<LSTM, NI>(acc, h, c);
         split_state<NI, F16, (TERMS > 4)>(b, h);                     // for this step's head and the next step's gates
         if (!LARGE) split_head_step<NI>(lacc, hw, h);
+    };
+    if (F16 && !LSTM) {
+        step(std::integral_constant<int, 1>{}, 0);
+        for (int t = 1; t < kT; ++t) step(std::integral_constant<int, 0>{}, t);
+    } else {
+        for (int t = 0; t < kT; ++t) step(std::integral_constant<int, 2>{}, t);
     }
     if (LARGE) lacc = split_tile_mfma<TERMS, NI, F16>(lacc, s_head + (kT - 1) * (kSplitTile / 4), b, lane);
     split_head_epilogue<LARGE, NI>(lacc, blob + L.tail, lane, w_first, n_windows, p_out, dec_out, mode, threshold,
@@ -788,10 +794,6 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
     const int q = lane >> 4, n = lane & 15;
     const long tile = (long)blockIdx.x * C::waves + (threadIdx.x >> 6);
     if (tile * C::wave_windows >= n_windows) return;             // wave-uniform, after the only barrier
-#if defined(VAD_PRIO_WIDE)
-    if (VAD_PRIO_WIDE == 1 && (threadIdx.x >> 6) >= C::waves / 2) __builtin_amdgcn_s_setprio(1);
-    if (VAD_PRIO_WIDE == 2 && (threadIdx.x >> 6) < C::waves / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     const float up = F16 ? blob[L.tail + kTailScale(LARGE)] : 1.0f, inv = F16 ? blob[L.tail + kTailScale(LARGE) + 1] : 1.0f;
     const WideSplitA a_lds = wide_split_a(lds, lane);
     const long w_first = tile * C::wave_windows + n;             // the lane's windows: w_first (and w_first + 16)
@@ -832,10 +834,17 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) head2[ni][0] = head2[ni][1] = 0.0f;
 
-    for (int t = 0; t < kT; ++t) {
+    // One step.  The first step has no recurrent product (the state is zero); it is peeled off the loop so that the
+    // loop body has no branch around its matrix work: with one, every accumulator is a merge of two paths, and the
+    // copies and the registers that costs stay in the hot loop (the float16 form spilled 15 registers and needed 116 ms
+    // per 100 h for hidden 90; without the branch 0 and 100 ms).  The row requests are unconditional for the same
+    // reason (past the last step they re-read the last row, clamped, and nothing uses it).
+    auto step = [&](auto first_step, const int t) __attribute__((always_inline)) {
+        constexpr bool kFirst = decltype(first_step)::value;
         // the row the wave's last window consumes at the next step
         const long rn = tile * C::wave_windows + (C::wave_windows - 1) + t + 1;
         const float* nxt = gi + (rn < last_row ? rn : last_row) * kRow + chunk;
+        // The rows of tile mt move down a lane and the last window's next row is requested: in flight until the next step.
         auto next_rows = [&](int mt) {
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
@@ -851,15 +860,30 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
                 }
             }
         };
-        SplitHeadWeights hw[UT];                                 // 2-row head: vector ALU, float32 weights
-        if (!LARGE) {
-#pragma unroll
-            for (int kb = 0; kb < UT; ++kb) split_head_load(hw[kb], a1 + kb * kHk * 64, t * UT, lane);
-        }
         TL_STAMP(0);
 #pragma unroll
         for (int mt = 0; mt < UT; ++mt) {
             WideTile<NI> acc[4];
+            // The tile's 6 UT operand units (gate, row group, k-block: a hi, mid and lo entry, TERMS products) stream through
+            // a ring of three: unit u + 2 is requested from LDS before unit u's products are issued, so the reads of two
+            // units are in flight behind the matrix work and no product waits for a whole LDS round trip (left to the
+            // compiler, a wave drained its LDS queue about every six products: hidden 90 100 -> 94 ms per 100 h).
+            struct AUnit {
+                u32x4 h, m, l;
+            };
+            constexpr int kRing = 3, kUnits = 6 * UT;
+            AUnit ring[kRing];
+            auto fetch = [&](int u, AUnit& o) {
+                const int base = wide_split_base(UT, u / (2 * UT), mt, (u / UT) & 1, u % UT);
+                o.h = wide_split_entry(a_lds, base * 2 + 0);
+                o.m = wide_split_entry(a_lds, base * 2 + 1);
+                if (TERMS > 4 && kHm + base < kLdsEntries) o.l = wide_split_entry(a_lds, kHm + base);
+            };
+            if (!kFirst) {
+#pragma unroll
+                for (int u = 0; u + 1 < kRing; ++u) fetch(u, ring[u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc[g] = row[g * UT + mt];
 #pragma unroll
@@ -868,35 +892,29 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[3].v[mi][ni] = v;
             }
-            if (t > 0) {
-                // the entries that LDS has no room for (the tail of the last gate's lo terms): requested a gate ahead of
-                // the one that uses them
+            if (!kFirst) {
                 u32x4 far[2][UT];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    WideTile<NI>& dst = acc[g == 2 ? 3 : g];
-                    __builtin_amdgcn_sched_barrier(0);           // one gate's operand reads at a time
-                    if (g == 1) {
+                for (int u = 0; u < kUnits; ++u) {
+                    const int g = u / (2 * UT), mi = (u / UT) & 1, kb = u % UT;
+                    if (u == 2 * UT) {
+                        // the entries that LDS has no room for (the tail of the last gate's lo terms): requested from the
+                        // weight blob a gate ahead of the one that uses them
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
+                        for (int fm = 0; fm < 2; ++fm)
 #pragma unroll
-                            for (int kb = 0; kb < UT; ++kb) {
-                                const int e = kHm + wide_split_base(UT, 2, mt, mi, kb);
-                                if (TERMS > 4 && e >= kLdsEntries) far[mi][kb] = far_base[(e - kLdsEntries) * 64];
+                            for (int fk = 0; fk < UT; ++fk) {
+                                const int e = kHm + wide_split_base(UT, 2, mt, fm, fk);
+                                if (TERMS > 4 && e >= kLdsEntries) far[fm][fk] = far_base[(e - kLdsEntries) * 64];
                             }
                     }
-#pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) {
-                        if (F16 && mi) __builtin_amdgcn_sched_barrier(0);   // half a gate's operand reads at a time
-#pragma unroll
-                        for (int kb = 0; kb < UT; ++kb) {
-                            const int base = wide_split_base(UT, g, mt, mi, kb);
-                            const u32x4 ah = wide_split_entry(a_lds, base * 2 + 0), am = wide_split_entry(a_lds, base * 2 + 1);
-                            u32x4 al = ah;
-                            if (TERMS > 4) al = kHm + base < kLdsEntries ? wide_split_entry(a_lds, kHm + base) : far[mi][kb];
-                            wide_split_terms<UT, NI, TERMS, F16>(dst.v[mi], ah, am, al, b, kb);
-                        }
-                    }
+                    if (u + kRing - 1 < kUnits) fetch(u + kRing - 1, ring[(u + kRing - 1) % kRing]);
+                    __builtin_amdgcn_sched_barrier(0);           // the reads above go out before this unit's products
+                    const AUnit& o = ring[u % kRing];
+                    const bool is_far = TERMS > 4 && kHm + wide_split_base(UT, g, mt, mi, kb) >= kLdsEntries;
+                    wide_split_terms<UT, NI, TERMS, F16>(acc[g == 2 ? 3 : g].v[mi], o.h, o.m,
+                                                         TERMS > 4 ? (is_far ? far[mi][kb] : o.l) : o.h, b, kb);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             TL_STAMP(1 + 4 * mt);                               // matrix work issued
@@ -923,26 +941,47 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
                         }
                         h[mt].v[mi][ni][i] = fmaf(z, h[mt].v[mi][ni][i] - nn, nn);   // in place: the products read the split copy
                     }
-            // The tile's rows move down a lane and the last window's next row is requested: in flight until the next
-            // step.  The last tile's request waits until the head is done: the head's operands come from global memory
-            // too, the memory counter retires in order, and waiting for them right after this request would mean
-            // waiting for a row that is not needed for another two thirds of a step.
+            // The last tile's request waits until the head is done: the head's operands come from global memory too, the
+            // memory counter retires in order, and waiting for them right after this request would mean waiting for a
+            // row that is not needed for another two thirds of a step.
             TL_STAMP(3 + 4 * mt);                               // gate math done
-            if (t + 1 < kT && mt + 1 < UT) next_rows(mt);
+            if (mt + 1 < UT) next_rows(mt);
             TL_STAMP(4 + 4 * mt);
         }
         if (F16) __builtin_amdgcn_sched_barrier(0);              // (the conversions interleaved with the gate math spill)
+        // The 26-row head's operands of this step come from the weight blob (L2): a row group's nine entries are requested
+        // at once, in registers the gate accumulators have just left and before the state is split, so the step waits
+        // for two round trips instead of one per k-block (all eighteen at once need 72 registers and gain nothing more).
+        constexpr int kHeadTerms = TERMS > 4 ? 3 : 2;
+        u32x4 he[UT][3];
+        auto head_request = [&](int mi) {
+#pragma unroll
+            for (int kb = 0; kb < UT; ++kb) {
+                const u32x4* e = a_head + (size_t)(((t * 2 + mi) * UT + kb) * 3) * 64 + lane;
+#pragma unroll
+                for (int k = 0; k < kHeadTerms; ++k) he[kb][k] = e[64 * k];
+            }
+        };
+        SplitHeadWeights hw[UT];                                 // 2-row head: vector ALU, float32 weights
+        if (LARGE) {
+            head_request(0);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < UT; ++kb) split_head_load(hw[kb], a1 + kb * kHk * 64, t * UT, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         wide_split_state<UT, NI, F16, (TERMS > 4)>(b, h);         // for this step's head and the next step's gates
         TL_STAMP(13);
         if (LARGE) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kb = 0; kb < UT; ++kb) {
-                    if (F16) __builtin_amdgcn_sched_barrier(0);      // one k-block's operand requests at a time
-                    const u32x4* e = a_head + (size_t)(((t * 2 + mi) * UT + kb) * 3) * 64 + lane;
-                    wide_split_terms<UT, NI, TERMS, F16>(lacc.v[mi], e[0], e[64], TERMS > 4 ? e[128] : e[0], b, kb);
-                }
+                for (int kb = 0; kb < UT; ++kb)
+                    wide_split_terms<UT, NI, TERMS, F16>(lacc.v[mi], he[kb][0], he[kb][1], he[kb][TERMS > 4 ? 2 : 0], b, kb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (mi == 0) head_request(1);
+            }
         } else {
 #pragma unroll
             for (int kb = 0; kb < UT; ++kb)
@@ -958,9 +997,11 @@ __global__ __launch_bounds__(WideSplitCfg<NI>::waves * 64) void gru_wide_split_k
         }
         __builtin_amdgcn_sched_barrier(0);                       // keep the request below the head's waits
         TL_STAMP(14);
-        if (t + 1 < kT) next_rows(UT - 1);
+        next_rows(UT - 1);
         TL_STAMP(15);
-    }
+    };
+    step(std::true_type{}, 0);
+    for (int t = 1; t < kT; ++t) step(std::false_type{}, t);
     // epilogue in the layout split_head_epilogue reads (element (mi, ni, i) = split_index; 2-row head: elements 2 ni, 2 ni + 1)
     f32x16 out;
 #pragma unroll
@@ -1020,14 +1061,21 @@ constexpr int wide_split_lds_floats(int ut, int terms) {
 constexpr int kWideSplitNi = 1;       // window halves per lane of gru_wide_split_kernel: 16 windows per wave, two waves per SIMD
                                       // (2 = 32 windows per wave, one wave per SIMD with all 512 registers: measured 199 vs 148 ms)
 
+// The 2-row head on 65..96 units (no model of the reference has it) does not fit 256 registers in the bfloat16 forms
+// (more than 100 spilled): those take the float32 workspace kernel, which is what the spilling kernel's time came to.
+template <bool LARGE, int UT, bool F16>
+constexpr bool wide_split_built() { return LARGE || UT < 3 || F16; }
+
 template <bool LARGE, int UT>
 int allow_wide_split() {
     int rc = VAD_OK;
     for (int mode : kSplitModes)
         dispatch_split_mode(mode, [&](auto terms, auto f16) {
-            if (rc == VAD_OK)
-                rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, decltype(terms)::value, kWideSplitNi, decltype(f16)::value>,
-                               wide_split_lds_floats(UT, decltype(terms)::value));
+            if constexpr (wide_split_built<LARGE, UT, decltype(f16)::value>()) {
+                if (rc == VAD_OK)
+                    rc = allow_lds(&gru_wide_split_kernel<LARGE, UT, decltype(terms)::value, kWideSplitNi, decltype(f16)::value>,
+                                   wide_split_lds_floats(UT, decltype(terms)::value));
+            }
         });
     return rc;
 }
@@ -1111,16 +1159,17 @@ int launch_wide(const float* x, long n_windows, WindowMap wm, const float* blob,
                                ws.ptr, f16 ? L.tail + kTailScale(LARGE) : -1);
             using SC = WideSplitCfg<kWideSplitNi>;
             const long sblocks = (nw + SC::waves * SC::wave_windows - 1) / (SC::waves * SC::wave_windows);
-            if (matrix_mode == VAD_MATRIX_F32)
+            if (matrix_mode == VAD_MATRIX_F32 || !(f16 ? wide_split_built<LARGE, UT, true>() : wide_split_built<LARGE, UT, false>()))
                 hipLaunchKernelGGL((gru_wide_stream_kernel<LARGE, UT, KL>), dim3((unsigned)blocks), dim3(64 * kWavesPerBlock),
                                    lds_bytes, st, ws.ptr, nw, blob, p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
             else
-                dispatch_split_mode(matrix_mode, [&](auto terms, auto f16) {
+                dispatch_split_mode(matrix_mode, [&](auto terms, auto f16_mode) {
                     constexpr int kTerms = decltype(terms)::value;
-                    hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, kTerms, kWideSplitNi, decltype(f16)::value>),
-                                       dim3((unsigned)sblocks), dim3(64 * SC::waves),
-                                       (size_t)wide_split_lds_floats(UT, kTerms) * sizeof(float), st, ws.ptr, nw, blob,
-                                       p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
+                    if constexpr (wide_split_built<LARGE, UT, decltype(f16_mode)::value>())
+                        hipLaunchKernelGGL((gru_wide_split_kernel<LARGE, UT, kTerms, kWideSplitNi, decltype(f16_mode)::value>),
+                                           dim3((unsigned)sblocks), dim3(64 * SC::waves),
+                                           (size_t)wide_split_lds_floats(UT, kTerms) * sizeof(float), st, ws.ptr, nw, blob,
+                                           p + 2 * w0, dec ? dec + w0 : nullptr, mode, threshold);
                 });
             VAD_HIP_CHECK(hipGetLastError());
         }
