@@ -49,13 +49,12 @@ using namespace fe;
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;                            // the block's waves share the twiddle and DCT tables, nothing else
+constexpr int kWavesPerBlock = 4;                            // the block's waves share the DCT table, nothing else
 constexpr int kThreads = 64 * kWavesPerBlock;
-constexpr int kTwBytes = kTwFloat2s * 8;                     // block-shared twiddle tables
 constexpr int kRingRows = 3 * kFramesPerWave;                // MFCC rows a wave keeps for the delta stencil
 constexpr int kRingBytes = kRingRows * kNCep * 4;
 constexpr int kDctBytes = kDctSteps * 64 * 8;                // block-shared B operands of the DCT matrix product
-constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes + kDctBytes;
+constexpr int kSmemBytes = kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kDctBytes;
 constexpr int kWavesPerSimd = 3;                             // register budget 168; three 52 KB blocks per CU
 constexpr int kDeltaReach = 2;                               // delta(feat, 2) looks two rows to either side
 constexpr int kMaxRunFrames = 256;                           // frames one wave computes for one run, halo rows included
@@ -108,19 +107,14 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
     float* en = reinterpret_cast<float*>(wbase + kExBytes);                  // [4 frames][32]
     float* parts = reinterpret_cast<float*>(wbase + kPartOffset);            // [2][64], inside the exchange region
     float* ring = reinterpret_cast<float*>(wbase + kWaveLdsBytes);           // [kRingRows][12]
-    const float2* tws = reinterpret_cast<const float2*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
-    const double* dctb = reinterpret_cast<const double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
+    const double* dctb = reinterpret_cast<const double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
     const int off512 = tab->pow_off_512;
 
     LaneConst K;
     load_lane_const(K, tab, lane);
     {
-        // tw1 is the first member of MfccTables
-        const float4* src = reinterpret_cast<const float4*>(tab);
-        float4* dst = reinterpret_cast<float4*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
-        for (int i = threadIdx.x; i < kTwFloat2s / 2; i += kThreads) dst[i] = src[i];
         const double* dsrc = &tab->dctb[0][0];
-        double* ddst = reinterpret_cast<double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes) + kTwBytes);
+        double* ddst = reinterpret_cast<double*>(smem + kWavesPerBlock * (kWaveLdsBytes + kRingBytes));
         for (int i = threadIdx.x; i < kDctSteps * 64; i += kThreads) ddst[i] = dsrc[i];
         __syncthreads();
     }
@@ -180,7 +174,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void mfcc_kernel(const int
                 FE_STAMP(0);
                 frame_load(raw, slice_dwords + (long)j * (kFrame / 2) + lane, j == 0, lane);
                 if (it > 0) filter_sums(parts, en + (it - 1) * 32, K);      // the previous frame's, under this load
-                frame_energies(raw, tws, off512, K, ex, parts);
+                frame_energies(raw, off512, K, ex, parts);
                 FE_STAMP(9);
                 if (it + 1 < kFramesPerWave && j + 1 < last) FE_NEXT_FRAME();
             }

@@ -158,14 +158,11 @@ constexpr int kPartOffset = kPowFloats * 4;
 constexpr int kWaveLdsBytes = kExBytes + kEnBytes;
 static_assert(kPartOffset + kPartBytes <= kExBytes, "the power spectrum and the partial sums must fit the exchange region");
 
-// Block-shared LDS image of the W1024 twiddles tw1[15][64] (the head of MfccTables); the other two sets
-// live in registers.
-constexpr int kTwFloat2s = 15 * 64;
-
-// Loop-invariant per-lane constants that stay in registers (the twiddles do not: see frame_energies).
+// Loop-invariant per-lane constants that stay in registers.
 struct LaneConst {
-    float2 tw2[15];                           // s_a W64^(a q) of this lane's a  } the twiddle sets that fit the
-    float2 twr[8];                            // W2048^fft_bin(lane, u)          } registers at 3 waves per SIMD
+    float2 tw1[15];                           // W1024^(lane k1)                 } all three twiddle sets: 76 of the
+    float2 tw2[15];                           // s_a W64^(a q) of this lane's a  } 168 registers three waves per SIMD
+    float2 twr[8];                            // W2048^fft_bin(lane, u)          } leave a wave
     unsigned pow_lo[8], pow_hi[8];            // byte offsets of the lane's bins in the power-spectrum image
     int run_count;
     float run_inv, run_w0, run_f0;
@@ -175,6 +172,8 @@ struct LaneConst {
 __device__ __forceinline__ void load_lane_const(LaneConst& K, const MfccTables* __restrict__ tab, int lane) {
 #pragma unroll
     for (int k = 0; k < 15; ++k) K.tw2[k] = tab->tw2[k][lane & 3];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) K.tw1[k] = tab->tw1[k][lane];
 #pragma unroll
     for (int j = 0; j < 8; ++j) K.twr[j] = tab->twr[j][lane];
 #pragma unroll
@@ -220,14 +219,14 @@ __device__ __forceinline__ void frame_load(RawFrame& raw, const int* __restrict_
 
 // One frame from its raw input to the mel partial sums of the 64 run-lanes in parts[0..63] (rising edges) and
 // parts[64..127] (falling edges); filter_sums turns them into the 26 filter energies.
-// The W1024 twiddle factors are read from `tws`, a block-shared LDS image of the table, where they are used
-// instead of living in 30 registers: three waves per SIMD need the register file, and reading them from
-// global memory instead makes the kernel texture-path-bound (measured 2.2x slower).
+// The W1024 twiddle factors live in 30 registers (K.tw1).  They used to be read from a block-shared LDS image while the
+// mel stage still needed the registers; with 37 freed there, taking the 15 reads per frame off the LDS array is worth
+// 16.4 -> 15.9 ms per 100 h (reading them from global memory makes the kernel texture-path-bound: 2.2x slower).
 // `off512` is MfccTables::pow_off_512.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2* tws, int off512, const LaneConst& K,
+__device__ __forceinline__ void frame_energies(const RawFrame& raw, int off512, const LaneConst& K,
                                                float2* ex, float* parts) {
     const int lane = fresh_lane();
     const int k1l = lane >> 2, al = lane & 3;
@@ -252,7 +251,7 @@ __device__ __forceinline__ void frame_energies(const RawFrame& raw, const float2
     //      twiddle W1024^(n2 k1) ----
     dft16(v);
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tws[(k - 1) * 64 + lane]);
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], K.tw1[k - 1]);
 
     // ---- the exchange: [k1][n2] -> lane (k1, a) reads n2 = a + 4 b, b = 0..15 ----
 #pragma unroll

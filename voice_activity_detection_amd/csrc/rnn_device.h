@@ -177,19 +177,8 @@ template <bool F16, bool WITH_LO>
 __device__ __forceinline__ SplitTerms split_pair(float x0, float x1) {
     unsigned hi, mid, lo = 0;
     if (F16) {
-        // x - (float)f16(x) is exact
-#if defined(VAD_F16_SPLIT_PLAIN)
-        const f16x2 h = __builtin_convertvector(f32x2s{x0, x1}, f16x2);
-        const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
-        const f16x2 m = __builtin_convertvector(f32x2s{r0, r1}, f16x2);
-        hi = __builtin_bit_cast(unsigned, h);
-        mid = __builtin_bit_cast(unsigned, m);
-        if (WITH_LO) {
-            const float q0 = r0 - (float)m[0], q1 = r1 - (float)m[1];
-            lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{q0, q1}, f16x2));
-        }
-#else
-        // the residuals by v_fma_mix_f32: a float32 fma whose first operand is read as the low / high float16 of a dword
+        // x - (float)f16(x) is exact; the residuals by v_fma_mix_f32, a float32 fma whose first operand is read as the
+        // low / high float16 of a dword
         hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{x0, x1}, f16x2));
         float r0, r1;
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(x0));
@@ -201,7 +190,6 @@ __device__ __forceinline__ SplitTerms split_pair(float x0, float x1) {
             asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(mid), "v"(r1));
             lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{q0, q1}, f16x2));
         }
-#endif
     } else {
         const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xFFFF0000u);
         const float r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xFFFF0000u);
