@@ -244,6 +244,24 @@ int vad_set_matrix_mode(int mode);
 int vad_get_matrix_mode(void);
 
 /*
+ * Net.forward (core/models.py:39-81) for inputs that are not (B,30,24) windows.  The reference widens a 2-D input
+ * (A,24) to A sequences of one step and a 1-D input to one sequence of one step (core/models.py:44-47), runs its
+ * recurrent layer over any sequence length and re-cuts ALL hidden states, in (sequence, step) order, into rows of 900
+ * values (view(-1, FRAMES ** 2), core/models.py:66) before the head.  This entry point does the same for n_seq
+ * sequences of seq_len steps (hidden size 30): p_dev receives n_seq * seq_len / 30 posterior rows; a product that
+ * is not a multiple of 30 is VAD_EINVAL, where the reference's view() raises.  Weights are device copies of the
+ * state dict in PyTorch's own layout (rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0; head:
+ * lin1.weight, lin1.bias, lin2.weight, lin2.bias for large != 0, else lin.weight, lin.bias and two NULLs).
+ * hseq_dev is scratch for n_seq * seq_len * 30 floats.  A plain kernel for completeness of the drop-in, not a tuned
+ * one: windows go through vad_gru_forward_f32 / vad_lstm_forward_f32.
+ */
+int vad_net_forward_seq_f32(const float* x_dev, int64_t n_seq, int64_t seq_len,
+                            const float* w_ih_dev, const float* w_hh_dev, const float* b_ih_dev, const float* b_hh_dev,
+                            const float* head_w1_dev, const float* head_b1_dev,
+                            const float* head_w2_dev, const float* head_b2_dev,
+                            int lstm, int large, float* hseq_dev, float* p_dev, void* stream);
+
+/*
  * vad_gru_forward_ws_f32 / vad_lstm_forward_f32 with the matrix mode as an argument of the call instead of the
  * process-wide setting, so that models (or callers, or streams) of one process can differ in it: one model
  * bit-identical to its dense-batch forward() (VAD_MATRIX_F32), another on the faster split products.

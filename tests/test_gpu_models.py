@@ -229,9 +229,12 @@ def test_weight_updates_are_picked_up(vad):
 def test_bad_shapes_raise(vad):
     net = vad.Net(large=False, lstm=True)
     with pytest.raises(RuntimeError):
-        net(torch.zeros(4, 29, 24))
+        net(torch.zeros(4, 29, 24))                     # 116 hidden states: the reference's view(-1, 900) fails
     with pytest.raises(RuntimeError):
-        net(torch.zeros(30, 24))
+        net(torch.zeros(31, 24))
+    assert net(torch.zeros(30, 24)).shape == (1, 2)     # 30 one-step sequences: one row in the reference too
+    with pytest.raises(RuntimeError):
+        vad.DenseNet()(torch.zeros(30, 24))
 
 
 def test_model_stack_names(vad):
@@ -608,3 +611,26 @@ def test_float16_modes_take_outsized_weights(vad):
     for mode in ('f16x6', 'f16x4', 'bf16x8'):
         p, _ = net.score(feat, window_stride=24, matrix_mode=mode)
         assert bool(torch.isfinite(p).all()) and float((p - p32).abs().max()) <= ATOL, mode
+
+
+@pytest.mark.parametrize('kind', list(NET_KINDS))
+def test_forward_takes_every_input_shape_the_reference_does(vad, golden_dir, kind):
+    """Net.forward on inputs that are not (B,30,24) windows, against outputs of the reference itself
+    (tests/golden/make_seq_fixtures.py): 2-D rows as one-step sequences, sequences of 15 and 45 steps re-cut into
+    rows of 900 hidden values, and RuntimeError where the reference's view() raises."""
+    sd, _, _ = _fixture(golden_dir, kind)
+    fx = np.load(os.path.join(golden_dir, 'model_seq_shapes.npz'))
+    net = _make(vad, kind)
+    net.load_state_dict(sd)
+    for name in ('x2d', 'x15', 'x45', 'x1'):
+        want = fx['%s.%s' % (kind, name)]
+        got = net(torch.from_numpy(fx[name])).cpu().numpy()
+        assert got.shape == want.shape, name
+        assert np.abs(got - want).max() <= ATOL, (name, np.abs(got - want).max())
+    # the window path and the sequence path agree on windows given as 30-step sequences of another batch shape
+    x = torch.from_numpy(fx['x45'][:, :30].copy())
+    assert np.abs(net(x).cpu().numpy() - net(x.reshape(4, 15, 24)).cpu().numpy()).max() > 0     # different cuts differ
+    for bad in (torch.zeros(24), torch.zeros(1, 7, 24), torch.zeros(2, 30, 23)):
+        with pytest.raises(RuntimeError):
+            net(bad)
+    assert net(torch.zeros(0, 5, 24)).shape == (0, 2)

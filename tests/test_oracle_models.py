@@ -57,3 +57,26 @@ def test_model_stack_names(golden_dir):
     with open(os.path.join(golden_dir, 'model_stack_names.txt')) as f:
         names = [line.split()[0] for line in f]
     assert names == ['net', 'net_large', 'densenet', 'densenet_large']
+
+
+SEQ_INPUTS = ['x2d', 'x15', 'x45', 'x1']
+
+
+@pytest.mark.parametrize('kind', KINDS[:4])
+def test_oracle_reproduces_reference_on_other_input_shapes(golden_dir, kind):
+    """Inputs that are not (B,30,24) windows (tests/golden/make_seq_fixtures.py): 2-D rows become one-step sequences
+    (core/models.py:44-47) and all hidden states are re-cut into rows of 900 (core/models.py:66); a 1-D input and a
+    sequence count the cut does not divide raise, as in the reference."""
+    z, _ = _load(golden_dir, kind)
+    fx = np.load(os.path.join(golden_dir, 'model_seq_shapes.npz'))
+    net = models_ref.make_model(kind)
+    models_ref.load_state_dict_numpy(net, z)
+    with torch.no_grad():
+        for name in SEQ_INPUTS:
+            y = net(torch.from_numpy(fx[name])).numpy()
+            np.testing.assert_allclose(y, fx['%s.%s' % (kind, name)], rtol=0, atol=1e-6, err_msg=name)
+        for bad in (torch.zeros(24), torch.zeros(1, 7, 24)):
+            with pytest.raises(RuntimeError, match='invalid for input of size'):
+                net(bad)
+    assert 'invalid for input of size 30' in str(fx['%s.raises_1d' % kind])
+    assert 'invalid for input of size 210' in str(fx['%s.raises_7' % kind])

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAD_AMD_LIB') or os.path.join(_HERE, 'libvad_amd.so')
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
-SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip', 'nicknet.hip', 'overlay.hip', 'sweep.hip']
+SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip', 'nicknet.hip', 'overlay.hip', 'sweep.hip', 'seq.hip']
 HEADERS = ['vad_internal.h', 'mfcc_device.h', 'rnn_device.h']
 
 # every symbol include/vad_amd.h declares
@@ -27,7 +27,7 @@ SYMBOLS = [
     'vad_synth_audio_i16', 'vad_overlay_i16', 'vad_threshold_sweep_f32', 'vad_threshold_sweep_noalloc_f32',
     'vad_set_matrix_mode', 'vad_get_matrix_mode', 'vad_gru_forward_mode_f32', 'vad_lstm_forward_mode_f32', 'vad_gru_forward_rows_f32', 'vad_lstm_forward_rows_f32', 'vad_densenet_forward_rows_f32',
     'vad_nicknet_blob_floats', 'vad_nicknet_tensor_count', 'vad_pack_nicknet_weights', 'vad_nicknet_forward_f32',
-    'vad_nicknet_forward_rows_f32', 'vad_nicknet_stages_f32', 'vad_nicknet_embed_f32',
+    'vad_nicknet_forward_rows_f32', 'vad_nicknet_stages_f32', 'vad_nicknet_embed_f32', 'vad_net_forward_seq_f32',
 ]
 
 
@@ -104,6 +104,8 @@ def lib():
     L.vad_gru_forward_mode_f32.argtypes = fwd[:-1] + [ctypes.c_int, c_void, ctypes.c_size_t, c_void]
     L.vad_lstm_forward_mode_f32.restype = ctypes.c_int
     L.vad_lstm_forward_mode_f32.argtypes = fwd[:-1] + [ctypes.c_int, c_void]
+    L.vad_net_forward_seq_f32.restype = ctypes.c_int
+    L.vad_net_forward_seq_f32.argtypes = [c_void, c_i64, c_i64] + [c_void] * 8 + [ctypes.c_int, ctypes.c_int, c_void, c_void, c_void]
     L.vad_gru_workspace_bytes.restype = ctypes.c_size_t
     L.vad_gru_workspace_bytes.argtypes = [ctypes.c_int, c_i64]
     L.vad_densenet_forward_f32.restype = ctypes.c_int

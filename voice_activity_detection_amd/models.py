@@ -154,8 +154,8 @@ class _HipModule(nn.Module):
         return p, d
 
     def forward(self, x):
-        # core/models.py:44-47 widens 1-D / 2-D inputs to a batch of length-1 sequences; the
-        # reference's own view(-1, 900) then only works for 30-step windows, which is all it is fed.
+        # (Net overrides this for the other shapes core/models.py:44-66 accepts; the convolutional models only
+        # work on 30-step windows in the reference too.)
         if x.dim() != 3 or x.size(1) != FRAMES or x.size(2) != FEATURES:
             raise RuntimeError('expected input of shape (batch, %d, %d), got %s'
                                % (FRAMES, FEATURES, tuple(x.shape)))
@@ -256,6 +256,44 @@ class Net(_HipModule):
         fn = L.vad_lstm_forward_rows_f32 if self.lstm else L.vad_gru_forward_rows_f32
         return fn(f_ptr, n_rows, r_ptr, n, blob_ptr, self.rnn.hidden_size, int(self.large), p_ptr, d_ptr, mode, thr,
                   stream)
+
+    def forward(self, x):
+        """core/models.py:39-81.  (B,30,24) windows take the window kernels; any other shape the reference accepts
+        -- 2-D (A,24) = A one-step sequences, 1-D, or (B,T,24) with B*T a multiple of 30 -- is run as sequences
+        whose hidden states are re-cut into rows of 900 exactly as the reference's view(-1, FRAMES ** 2) does, and
+        raises RuntimeError where that view (or torch's input-size check) would."""
+        if x.dim() == 2:                                           # core/models.py:44-47
+            x = x.unsqueeze(1)
+        elif x.dim() == 1:
+            x = x.unsqueeze(0).unsqueeze(0)
+        if x.dim() == 3 and x.size(1) == FRAMES and x.size(2) == FEATURES:
+            return super().forward(x)
+        if x.dim() != 3 or x.size(2) != FEATURES:
+            raise RuntimeError('input.size(-1) must be equal to input_size. Expected %d, got %s'
+                               % (FEATURES, tuple(x.shape)))
+        H = self.rnn.hidden_size
+        if H != FRAMES:
+            raise RuntimeError('inputs other than (batch, %d, %d) windows need the reference\'s %d hidden units'
+                               % (FRAMES, FEATURES, FRAMES))
+        n_seq, seq_len = x.size(0), x.size(1)
+        if (n_seq * seq_len * H) % (FRAMES * FRAMES):
+            raise RuntimeError("shape '[-1, %d]' is invalid for input of size %d"
+                               % (FRAMES * FRAMES, n_seq * seq_len * H))
+        dev = _cuda_device()
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        sd = {k: v.detach().to(device=dev, dtype=torch.float32).contiguous() for k, v in self.state_dict().items()}
+        head = ('lin1.weight', 'lin1.bias', 'lin2.weight', 'lin2.bias') if self.large else ('lin.weight', 'lin.bias')
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+        head_ptrs = [ptr(sd[k]) for k in head] + [None] * (4 - len(head))
+        rows = n_seq * seq_len // FRAMES
+        hseq = torch.empty((max(n_seq * seq_len, 1), H), dtype=torch.float32, device=dev)
+        p = torch.empty((rows, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().vad_net_forward_seq_f32(
+                ptr(x), n_seq, seq_len, ptr(sd['rnn.weight_ih_l0']), ptr(sd['rnn.weight_hh_l0']),
+                ptr(sd['rnn.bias_ih_l0']), ptr(sd['rnn.bias_hh_l0']), *head_ptrs, int(self.lstm), int(self.large),
+                ptr(hseq), ptr(p), _lib.current_stream()))
+        return p
 
 
 class _DenseSingle(nn.Module):                 # parameter container, core/models.py:333-348
