@@ -23,7 +23,7 @@ def sequential():
     net.score(feat, window_stride=24, n_windows=n - 29, out=p, decisions=d)
 
 
-sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+sa, sb = torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)       # the model kernel's blocks go first
 
 
 def pipelined():

@@ -304,9 +304,10 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
     SplitB b;
 
     // One step.  kind 1: the first step (no recurrent product: the state is zero), 0: a later one, 2: either, decided by t.
-    // The float16 GRU peels the first step off the loop, so that its loop body has no branch around the matrix work and
-    // the accumulators are not merges of two paths (GRU-large 15.9 -> 15.3 ms per 100 h, GRU-small 15.4 -> 14.1); the
-    // LSTM and the bfloat16 forms gain nothing from it or lose (GRU-large bf16x8 16.6 -> 17.6 ms) and keep the branch.
+    // The float16 GRU with the 2-row head peels the first step off the loop, so that its loop body has no branch around
+    // the matrix work and the accumulators are not merges of two paths (GRU-small 15.5 -> 14.2 ms per 100 h).  The other
+    // forms gain nothing from it or lose (same device: GRU-large f16x6 14.9 ms with the branch, 15.4 peeled; bf16x8
+    // 16.6 -> 17.6) and keep the branch: what the compiler does with the freed registers decides, not the branch.
     auto step = [&](auto kind, const int t) __attribute__((always_inline)) {
         const bool with_product = decltype(kind)::value == 2 ? t > 0 : decltype(kind)::value == 0;
         SplitHeadWeights hw;                                     // 2-row head: vector ALU, float32 weights
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(SplitCfg<LSTM>::waves * 64) void rnn_stream_split_k
         split_state<NI, F16, (TERMS > 4)>(b, h);                     // for this step's head and the next step's gates
         if (!LARGE) split_head_step<NI>(lacc, hw, h);
     };
-    if (F16 && !LSTM) {
+    if (F16 && !LSTM && !LARGE) {
         step(std::integral_constant<int, 1>{}, 0);
         for (int t = 1; t < kT; ++t) step(std::integral_constant<int, 0>{}, t);
     } else {
