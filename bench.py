@@ -94,7 +94,7 @@ MODEL_KERNEL = {'gru_large': 'rnn_stream_kernel<false, true, 15>', 'gru_small': 
                 'lstm_large': 'rnn_stream_kernel<true, true, 15>', 'lstm_small': 'rnn_stream_kernel<true, false, 15>',
                 'gru_h90': 'gru_wide_stream_kernel<true, 3, 13>',
                 'densenet': 'densenet_stream_kernel<false>', 'densenet_large': 'densenet_stream_kernel<true>',
-                'nicknet': 'nicknet_kernel<true>', 'nicknet_small': 'nicknet_kernel<false>'}
+                'nicknet': 'nicknet_stream_kernel<true>', 'nicknet_small': 'nicknet_stream_kernel<false>'}
 
 
 DEFAULT_MODE = 'f16x6'

@@ -96,6 +96,32 @@ def test_sliding_and_sampled_windows_equal_explicit_windows(vad, size):
     assert torch.equal(d_thr, (p_slide[:, 1] >= np.float32(t)).to(torch.uint8))
 
 
+@pytest.mark.parametrize('size', ['large', 'small'])
+@pytest.mark.parametrize('n_rows', [30, 31, 45, 46, 61, 77, 158, 2077])
+def test_stream_kernel_is_bit_identical_at_ragged_sizes(vad, size, n_rows):
+    """Stride-1 windows take the kernel that evaluates the trunk once per row (interior positions) plus the
+    window-specific edge positions; dense batches take the per-window kernel.  Same instruction chains on the same
+    operands: equal bits, for every window count around the 16-window tiles and the 48-row span of a wave, with
+    guard elements behind the outputs."""
+    large = size == 'large'
+    ref = nicknet_ref.make_nicknet(large)
+    net = vad.NickNet(large=large)
+    net.load_state_dict(ref.state_dict())
+    rng = np.random.default_rng(n_rows)
+    feat = torch.from_numpy(rng.normal(0, 6, size=(n_rows, 24)).astype(np.float32)).cuda()
+    nw = n_rows - 29
+    p = torch.full((nw + 7, 2), -7.0, device='cuda')
+    d = torch.full((nw + 7,), 9, dtype=torch.uint8, device='cuda')
+    net.score(feat, window_stride=24, out=p[:nw], decisions=d[:nw])
+    idx = torch.arange(nw, device='cuda')[:, None] + torch.arange(30, device='cuda')[None, :]
+    p_batch, d_batch = net.score(feat[idx].contiguous())
+    assert torch.equal(p[:nw], p_batch) and torch.equal(d[:nw], d_batch)
+    assert bool((p[nw:] == -7.0).all()) and bool((d[nw:] == 9).all())
+    with torch.no_grad():
+        y = ref(feat[idx[:64]].cpu()).numpy()
+    assert np.abs(p[:min(nw, 64)].cpu().numpy() - y).max() <= ATOL
+
+
 def test_saturated_inputs_stay_finite(vad):
     """Large pre-activations saturate tanh / sigmoid (exp2 overflows to inf, its reciprocal is 0): no NaN."""
     ref = nicknet_ref.make_nicknet(True)

@@ -7,5 +7,5 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$root/variants"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xclang -target-feature -Xclang -packed-fp32-ops \
     -I"$root/include" -I"$src" "$@" -o "$root/variants/libvad_$name.so" \
-    "$src"/{abi,mfcc,rnn,densenet,nicknet,overlay,sweep,seq}.hip 2>&1 | grep -v "packed-fp32-ops" || true
+    "$src"/{abi,mfcc,rnn,densenet,nicknet,nicknet_stream,overlay,sweep,seq}.hip 2>&1 | grep -v "packed-fp32-ops" || true
 ls -la "$root/variants/libvad_$name.so"

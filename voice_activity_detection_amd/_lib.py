@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VAD_AMD_LIB') or os.path.join(_HERE, 'libvad_amd.so')
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
-SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip', 'nicknet.hip', 'overlay.hip', 'sweep.hip', 'seq.hip']
-HEADERS = ['vad_internal.h', 'mfcc_device.h', 'rnn_device.h']
+SOURCES = ['abi.hip', 'mfcc.hip', 'rnn.hip', 'densenet.hip', 'nicknet.hip', 'nicknet_stream.hip', 'overlay.hip', 'sweep.hip', 'seq.hip']
+HEADERS = ['vad_internal.h', 'mfcc_device.h', 'rnn_device.h', 'nicknet_device.h']
 
 # every symbol include/vad_amd.h declares
 SYMBOLS = [
