@@ -12,6 +12,7 @@ from .process_data import (add_noise, mfcc_delta_ragged, mfcc_delta_slices, mfcc
                            process_test_data, process_test_frames, process_training_data, recording_slices,
                            training_slices)
 from . import metrics
+from . import train
 from .generator import DataGenerator
 from .metrics import fix_frr, roc_curve, threshold_sweep
 from .stream import StreamWorkspace, vad_stream
@@ -20,6 +21,6 @@ from .synth import synth_audio, synth_stream
 
 __all__ = ['VadError', 'build', 'init', 'lib', 'Net', 'DenseNet', 'NickNet', 'MODEL_STACK', 'set_matrix_mode', 'process_test_frames', 'process_test_data', 'recording_slices', 'add_noise',
            'overlay', 'overlay_device', 'mfcc_delta_slices', 'mfcc_delta_stream', 'mfcc_delta_ragged', 'process_training_data', 'training_slices', 'vad_stream', 'StreamWorkspace',
-           'synth_audio', 'metrics', 'DataGenerator', 'fix_frr', 'roc_curve', 'threshold_sweep',
+           'synth_audio', 'metrics', 'train', 'DataGenerator', 'fix_frr', 'roc_curve', 'threshold_sweep',
            'synth_stream', 'SAMPLE_RATE', 'FRAME_SIZE', 'FRAMES', 'FEATURES', 'BATCH_SIZE', 'SLICE_MAX',
            'ALIGN_FRAMES', 'STEP_SIZE']
