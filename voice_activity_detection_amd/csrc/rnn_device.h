@@ -112,8 +112,27 @@ __device__ __forceinline__ float sigmoid_pre(float a) {       // a = -x log2 e  
 __device__ __forceinline__ float tanh_pre(float a) {          // a = 2 x log2 e  ->  1 - 2 / (1 + e^2x)
     return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)), 1.0f);
 }
-__device__ __forceinline__ float fast_tanh(float x) {
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+
+// One LSTM unit from its pre-scaled pre-activations (a_i, a_f, a_o times -log2 e, a_g times 2 log2 e): returns
+// `scale` * h' and sets c'.  With E_x = 2^a_x the cell is
+//     i g  = (E_g - 1) / ((1 + E_i)(1 + E_g)),   c' = c / (1 + E_f) + i g,   h' = (E_c - 1) / ((1 + E_o)(1 + E_c)),  E_c = e^(2 c'):
+// a product of a sigmoid and a tanh shares ONE reciprocal, so the unit costs 5 v_exp + 3 v_rcp instead of 5 + 5 (a
+// transcendental takes the issue slot of four plain instructions) at one more plain instruction.  Overflows stay
+// harmless: E_g is capped (its own infinity would meet a zero), an infinite E_i or E_o makes the reciprocal, and
+// with it the product, zero as the closed gate demands, and E_c is finite because |c'| <= 30 steps.
+static_assert(kT <= 40, "e^(2 c) must stay finite: |c| grows by at most 1 per step");
+__device__ __forceinline__ float lstm_cell(float ai, float af, float ag, float ao, float c, float scale, float& c_new) {
+    const float ei = __builtin_amdgcn_exp2f(ai);
+    const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(af));
+    const float eg = fminf(__builtin_amdgcn_exp2f(ag), 0x1p60f);
+    const float eo = __builtin_amdgcn_exp2f(ao);
+    const float tg = 1.0f + eg;
+    const float igg = (eg - 1.0f) * __builtin_amdgcn_rcpf(fmaf(ei, tg, tg));
+    const float cn = fmaf(fg, c, igg);
+    c_new = cn;
+    const float ec = __builtin_amdgcn_exp2f(2.8853900817779268f * cn);
+    const float tc = 1.0f + ec;
+    return fmaf(scale, ec, -scale) * __builtin_amdgcn_rcpf(fmaf(eo, tc, tc));
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -303,13 +322,9 @@ __device__ __forceinline__ void gate_update(const f32x16 (&acc)[4], f32x16& h, f
     for (int i = 0; i < 16; ++i) {
         if (NI == 1 && ((i >> 2) & 1)) continue;
         if (LSTM) {
-            const float ig = sigmoid_pre(acc[0][i]);
-            const float fg = sigmoid_pre(acc[1][i]);
-            const float gg = tanh_pre(acc[2][i]);
-            const float og = sigmoid_pre(acc[3][i]);
-            const float cn = fmaf(fg, c[i], ig * gg);
+            float cn;
+            h[i] = lstm_cell(acc[0][i], acc[1][i], acc[2][i], acc[3][i], c[i], 1.0f, cn);
             c[i] = cn;
-            h[i] = og * fast_tanh(cn);
         } else {
             const float r = sigmoid_pre(acc[0][i]);
             const float z = sigmoid_pre(acc[1][i]);
@@ -342,15 +357,9 @@ __device__ __forceinline__ void gate_update_scaled(const f32x16 (&acc_in)[4], f3
     for (int i = 0; i < 16; ++i) {
         if (NI == 1 && ((i >> 2) & 1)) continue;
         if (LSTM) {
-            const float ig = sigmoid_pre(acc[0][i] * inv);
-            const float fg = sigmoid_pre(acc[1][i] * inv);
-            const float gg = tanh_pre(acc[2][i] * inv);
-            const float og = sigmoid_pre(acc[3][i] * inv);
-            const float cn = fmaf(fg, c[i], ig * gg);
+            float cn;
+            h[i] = lstm_cell(acc[0][i], acc[1][i], acc[2][i], acc[3][i], c[i], kStateScale, cn);      // 2^14 h
             c[i] = cn;
-            // 2^14 tanh(c)
-            h[i] = og * fmaf(-2.0f * kStateScale, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * cn)),
-                             kStateScale);
         } else {
             const float r_inv = __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(acc[0][i] * inv), up, up));   // 2^-S r
             const float z = sigmoid_pre(acc[1][i] * inv);
