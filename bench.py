@@ -113,6 +113,14 @@ def model_peak(model, mode):
     vector work share one pipe (157.3 TF).  In the bf16 split modes the recurrent and 26-row head products run as
     9, 8, 6 or 4 bf16 / f16 partial products each on the 16-bit matrix pipe, beside the rest of the work (projection, gate
     math, 2-row head) on the float32 pipe: the slower of the two pipes bounds it."""
+    if model.startswith('nicknet'):
+        # whatever the mode: the products of a hidden state (recurrent, and the second layer's input) are six float16
+        # partial products on the 16-bit pipe, the rest is float32 MFMA / vector work
+        hidden, layers = (29, 2) if model == 'nicknet' else (21, 1)
+        total = FLOP_PER_WINDOW[model][0]
+        on_f16 = T * 3 * hidden * hidden * 2 * (2 * layers - 1)
+        seconds = max(on_f16 * 6 / (PEAK_BF16_TFLOPS * 1e12), (total - on_f16) / (PEAK_FP32_TFLOPS * 1e12))
+        return total / seconds / 1e12
     if mode == 'f32' or not split_mode_applies(model):
         return PEAK_FP32_TFLOPS
     gates = 4 if model.startswith('lstm') else 3

@@ -309,6 +309,9 @@ int vad_densenet_forward_rows_f32(const float* feat_dev, int64_t n_rows, const i
  * reference counterpart.  The conv trunk (core/models.py:308-323), the GRU (:151,162) and `embed` (:109-128)
  * do run in the reference and are what vad_nicknet_stages_f32 / vad_nicknet_embed_f32 expose for checking.
  * The head input used here is the final hidden state of every GRU layer, h_n.permute(1,0,2).reshape(B, L*H).
+ * Arithmetic: float32 operands and accumulation; the convolutions, the first GRU layer's input products and the head
+ * on the float32 MFMA, the GRU's other products (those of a hidden state) as six float16 partial products of exactly
+ * split operands on the 16-bit MFMA (what is dropped is below 2^-35 of a product).
  *
  * `tensors_host`: the float tensors of the module in state_dict() order, skipping num_batches_tracked:
  * per conv layer conv.0.weight (cout,cin,3), conv.0.bias, conv.1.{weight,bias,running_mean,running_var} and

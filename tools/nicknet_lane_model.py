@@ -4,13 +4,16 @@ The kernel keeps every layer output as a "tile": unit 16 b + 4 i + q in register
 q, window on the lane's low four bits.  A v_mfma_f32_16x16x4_f32 takes, for k-step ks, the value lane group q
 holds for that k-step (k = q) and leaves row 4 q' + i' of its 16 x 16 result in register i' of lane group q'.
 This module restates exactly that algebra with numpy (float64) on the blob vad_pack_nicknet_weights writes --
-table layout [group of 4 k-steps][out block][lane][4], bias tiles [block][q][i], the pre-scaled activations --
+table layout [group of 4 k-steps][out block][lane][4], the GRU's recurrent weights as float16 split operands of
+v_mfma_f32_16x16x32_f16 with their power-of-two scales, bias tiles [block][q][i], the pre-scaled activations --
 so the packer and the lane algebra can be checked against the oracle without a GPU
 (tests/test_nicknet_lane_model.py).
 """
 import numpy as np
 
 T, F, XK = 30, 24, 6
+SPLIT_BLOCK = 3 * 64 * 4                          # floats of one out block of a float16 split table
+STATE_SCALE = 2.0 ** 14                           # the split state is 2^14 h
 LOG2E = 1.4426950408889634
 
 
@@ -30,8 +33,13 @@ def groups(ks):
     return (ks + 3) // 4
 
 
+def last_width(ks):
+    """Floats per lane of a table's last group of k-steps: one or two k-steps are stored at that width."""
+    return {1: 1, 2: 2}.get(ks % 4, 4)
+
+
 def table_floats(ks, nout):
-    return groups(ks) * nout * 256
+    return (groups(ks) - 1) * nout * 256 + nout * 64 * last_width(ks)
 
 
 class Dims:
@@ -60,16 +68,19 @@ def layout(d):
         at += 3 * tap
     gout = 3 * n_blocks(d.hidden)
     for g in range(d.layers):
-        L['gru_ih', g] = at
-        at += table_floats(tile_ksteps(d.gru_in(g)), gout)
-        L['gru_hh', g] = at
-        at += table_floats(tile_ksteps(d.hidden), gout)
+        L['gru_ih', g] = at                       # layers above the first: a float16 split table like gru_hh
+        at += table_floats(tile_ksteps(d.gru_in(g)), gout) if g == 0 else gout * SPLIT_BLOCK
+        L['gru_hh', g] = at                       # float16 split table: [out block][hi, mid, lo][64 lanes] x 8 float16
+        at += gout * SPLIT_BLOCK
     for l in range(d.nc):
         L['conv_bias', l] = at
         at += 64
     for g in range(d.layers):
         L['gru_bias', g] = at
         at += 128
+    for g in range(d.layers):
+        L['gru_scale', g] = at                    # 2^-(14 + Sw), 2^Sw of gru_hh, then of a split gru_ih
+        at += 4
     L['lds'] = at
     for s in range(d.ne + 1):
         L['emb', s] = at
@@ -95,7 +106,10 @@ def kvals(tile, nu):
 def mm(acc, blob, off, nout, kv, at=lambda o: o):
     """acc[at(o)] (each [4 i][4 q][windows]) += table(out block o) . kv -- one MFMA per (group, k-step, out block)."""
     ks_total = len(kv)
-    tab = blob[off: off + table_floats(ks_total, nout)].reshape(groups(ks_total), nout, 64, 4).astype(np.float64)
+    full, lw = groups(ks_total) - 1, last_width(ks_total)
+    tab = np.zeros((groups(ks_total), nout, 64, 4))
+    tab[:full] = blob[off: off + full * nout * 256].reshape(full, nout, 64, 4)
+    tab[full, :, :, :lw] = blob[off + full * nout * 256: off + table_floats(ks_total, nout)].reshape(nout, 64, lw)
     for g in range(groups(ks_total)):
         for j in range(4):
             ks = 4 * g + j
@@ -105,6 +119,22 @@ def mm(acc, blob, off, nout, kv, at=lambda o: o):
                 a = tab[g, o, :, j].reshape(4, 16)                   # [k = lane group][row m]
                 res = np.einsum('km,kw->mw', a, kv[ks])              # (16 rows, windows)
                 acc[at(o)] += res.reshape(4, 4, -1).transpose(1, 0, 2)   # row 4 q' + i' -> [i'][q']
+    return acc
+
+
+def mm_split(acc, blob, off, nout, tile, unscale, at=lambda o: o):
+    """acc[at(o)] += unscale * (split table(out block o) . 2^14 tile): the recurrent product as the kernel forms it
+    with v_mfma_f32_16x16x32_f16 -- lane 16 qa + m of the A operand holds row m and k-slots 8 qa + j, which are the
+    units lane group qa keeps in register [j >> 2][j & 3]; the three float16 terms of a weight are summed here (their
+    six kept partial products differ from the full product by less than 2^-35 of it)."""
+    raw = blob[off: off + nout * SPLIT_BLOCK].view(np.uint16).view(np.float16).reshape(nout, 3, 64, 8).astype(np.float64)
+    a = raw.sum(axis=1).reshape(nout, 4, 16, 8)                           # [o][qa][row m][j]
+    for o in range(nout):
+        res = np.zeros((16, tile.shape[-1]))
+        for qa in range(4):
+            for j in range(8):
+                res += a[o, qa, :, j][:, None] * (STATE_SCALE * tile[j >> 2, j & 3, qa])[None, :]
+        acc[at(o)] += unscale * res.reshape(4, 4, -1).transpose(1, 0, 2)   # row 4 q' + i' -> [i'][q']
     return acc
 
 
@@ -174,9 +204,13 @@ def forward(blob, x, large):
             acc = np.zeros((4 * nb, 4, 4, B))
             for a in range(4):
                 acc[a * nb: a * nb + nb] = bias_tile(blob, L['gru_bias', g] + 32 * a, B)[:nb]
-            mm(acc, blob, L['gru_ih', g], 3 * nb, xin)
+            if g == 0:
+                mm(acc, blob, L['gru_ih', g], 3 * nb, xin)
+            else:
+                mm_split(acc, blob, L['gru_ih', g], 3 * nb, h[g - 1], float(blob[L['gru_scale', g] + 2]))
             if t > 0:
-                mm(acc, blob, L['gru_hh', g], 3 * nb, kvals(h[g], H), at=lambda o: o if o < 2 * nb else o + nb)
+                mm_split(acc, blob, L['gru_hh', g], 3 * nb, h[g], float(blob[L['gru_scale', g]]),
+                         at=lambda o: o if o < 2 * nb else o + nb)
             r, z = sigmoid_pre(acc[:nb]), sigmoid_pre(acc[nb:2 * nb])
             n = tanh_pre(r * acc[3 * nb:] + acc[2 * nb:3 * nb])
             h[g][:nb] = z * (h[g][:nb] - n) + n

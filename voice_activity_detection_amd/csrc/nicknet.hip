@@ -27,9 +27,12 @@
 // four k-steps per lane, in a block-shared LDS copy (147 KB for the large model: one block per CU, whose
 // waves stride over the window tiles of the launch).
 //
-// float32 MFMA is a k-ordered FMA chain: no reduced-precision operand anywhere.  tanh / sigmoid are
-// v_exp_f32 / v_rcp_f32 forms on pre-scaled pre-activations (the packer multiplies the sigmoid inputs'
-// weights by -log2 e and the tanh inputs' by 2 log2 e), as in the GRU / LSTM kernels.
+// float32 MFMA is a k-ordered FMA chain.  The products whose B operand is a hidden state -- the GRU's recurrent
+// products and the input products of its second layer -- run on the 16-bit matrix pipe instead, each float32
+// product as six float16 partial products of exactly split operands with float32 accumulation (what is left out is
+// below 2^-35 of a product; nicknet_device.h, rnn_device.h): 16 cycles per K = 32 instead of 8 x 32.  tanh / sigmoid
+// are v_exp_f32 / v_rcp_f32 forms on pre-scaled pre-activations (the packer multiplies the sigmoid inputs' weights
+// by -log2 e and the tanh inputs' by 2 log2 e), as in the GRU / LSTM kernels.
 
 
 #include <mutex>
@@ -87,8 +90,11 @@ __global__ __launch_bounds__(kWaves * 64) void nicknet_kernel(const float* __res
 #pragma unroll
             for (int s = 0; s < 3; ++s) ring[l][s].b[0] = ring[l][s].b[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         Tile h[D::layers];
+        SplitTile hs[D::layers];                                 // written by every step before it is read
 #pragma unroll
         for (int l = 0; l < D::layers; ++l) h[l].b[0] = h[l].b[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int l = 0; l < D::layers; ++l) hs[l].hi = hs[l].mid = hs[l].lo = rnn::u32x4{0u, 0u, 0u, 0u};
 
 #pragma unroll 1
         for (int p = 0; p < kT + NC - 1; ++p) {
@@ -136,17 +142,7 @@ __global__ __launch_bounds__(kWaves * 64) void nicknet_kernel(const float* __res
                     }
             }
             NN_STAGE_FENCE;
-            {
-                float xin[tile_ksteps(C)];
-                tile_kvals<C>(cur, xin);
-                gru_step<LARGE, 0>(h[0], xin, a_lane, lds, t == 0, q);
-            }
-            NN_STAGE_FENCE;
-            if constexpr (D::layers > 1) {
-                float xin[tile_ksteps(H)];
-                tile_kvals<H>(h[0], xin);
-                gru_step<LARGE, D::layers - 1>(h[D::layers - 1], xin, a_lane, lds, t == 0, q);
-            }
+            gru_layers<LARGE>(h, hs, cur, a_lane, lds, t == 0, q);
             if (so.seq && w < n_windows) {
 #pragma unroll
                 for (int blk = 0; blk < n_blocks(H); ++blk)
@@ -225,11 +221,13 @@ template <typename W>
 void put_table(float* dst, int ks_total, int nout, W weight) {       // weight(out block, row m, k-step, lane group) -> double
     for (int g = 0; g < groups(ks_total); ++g)
         for (int o = 0; o < nout; ++o)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 4; ++j) {
+            for (int lane = 0; lane < 64; ++lane) {
+                const int width = g < groups(ks_total) - 1 ? 4 : last_width(ks_total);
+                for (int j = 0; j < width; ++j) {
                     const int ks = 4 * g + j;
-                    dst[((g * nout + o) * 64 + lane) * 4 + j] = ks < ks_total ? (float)weight(o, lane & 15, ks, lane >> 4) : 0.0f;
+                    dst[entry_offset(ks_total, nout, g, o, lane) + j] = ks < ks_total ? (float)weight(o, lane & 15, ks, lane >> 4) : 0.0f;
                 }
+            }
 }
 
 template <typename B>
@@ -273,14 +271,43 @@ int pack(const float* const* t, float* blob) {
         idx += 4;
         const int in = D::gru_in(g);
         auto gate_scale = [](int gate) { return gate == 2 ? rnn::kTanhScale : rnn::kSigmoidScale; };
-        put_table(blob + LY.gru_ih[g], tile_ksteps(in), 3 * NB, [&](int o, int m, int ks, int qq) {
-            const int gate = o / NB, ou = out_unit(H, o % NB, m), iu = tile_unit(in, ks, qq);
-            return (ou < 0 || iu < 0) ? 0.0 : gate_scale(gate) * (double)w_ih[(gate * H + ou) * in + iu];
-        });
-        put_table(blob + LY.gru_hh[g], tile_ksteps(H), 3 * NB, [&](int o, int m, int ks, int qq) {
-            const int gate = o / NB, ou = out_unit(H, o % NB, m), iu = tile_unit(H, ks, qq);
-            return (ou < 0 || iu < 0) ? 0.0 : gate_scale(gate) * (double)w_hh[(gate * H + ou) * H + iu];
-        });
+        // A weight matrix (3 H x cols) that multiplies a hidden state: float16 split A operands of
+        // v_mfma_f32_16x16x32_f16.  Lane 16 qa + m holds row m of the out block and, as k-slots 8 qa + j, the units lane
+        // group qa keeps in register [j >> 2][j & 3] of a tile; times the largest power of two that keeps every weight
+        // under float16's 65504 (rnn_device.h).  scale[0] = 2^-(14 + Sw) undoes it and the state's 2^14.
+        auto put_split = [&](const float* wm, int cols, float* dst, float* scale) {
+            double wmax = 0.0;
+            for (int gate = 0; gate < 3; ++gate)
+                for (int i = 0; i < H * cols; ++i) wmax = fmax(wmax, fabs(gate_scale(gate) * (double)wm[gate * H * cols + i]));
+            int sw = 13;
+            while (sw > -100 && ldexp(wmax, sw) > 65000.0) --sw;
+            if (!(wmax - wmax == 0.0) || sw <= -100) return false;
+            uint16_t* out = reinterpret_cast<uint16_t*>(dst);
+            bool finite = true;
+            for (int o = 0; o < 3 * NB; ++o)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int gate = o / NB, ou = out_unit(H, o % NB, lane & 15);
+                        const int iu = 16 * (j >> 2) + 4 * (j & 3) + (lane >> 4);
+                        const float x = (ou < 0 || iu >= cols) ? 0.0f
+                                                               : (float)ldexp(gate_scale(gate) * (double)wm[(gate * H + ou) * cols + iu], sw);
+                        uint16_t t3[3];
+                        rnn::split3_host(x, true, t3, &finite);
+                        for (int term = 0; term < 3; ++term) out[((o * 3 + term) * 64 + lane) * 8 + j] = t3[term];
+                    }
+            scale[0] = ldexpf(1.0f, -(rnn::kStateShift + sw));
+            scale[1] = ldexpf(1.0f, sw);
+            return finite;
+        };
+        if (g == 0) {
+            put_table(blob + LY.gru_ih[g], tile_ksteps(in), 3 * NB, [&](int o, int m, int ks, int qq) {
+                const int gate = o / NB, ou = out_unit(H, o % NB, m), iu = tile_unit(in, ks, qq);
+                return (ou < 0 || iu < 0) ? 0.0 : gate_scale(gate) * (double)w_ih[(gate * H + ou) * in + iu];
+            });
+        } else if (!put_split(w_ih, in, blob + LY.gru_ih[g], blob + LY.gru_scale[g] + 2)) {
+            return VAD_EINVAL;
+        }
+        if (!put_split(w_hh, H, blob + LY.gru_hh[g], blob + LY.gru_scale[g])) return VAD_EINVAL;
         float* bt = blob + LY.gru_bias[g];
         put_bias(bt, H, [&](int u) { return rnn::kSigmoidScale * ((double)b_ih[u] + (double)b_hh[u]); });
         put_bias(bt + kBiasTile, H, [&](int u) { return rnn::kSigmoidScale * ((double)b_ih[H + u] + (double)b_hh[H + u]); });

@@ -10,6 +10,7 @@
 namespace vad {
 namespace nn {
 
+using rnn::f16x8;
 using rnn::sigmoid_pre;
 using rnn::tanh_pre;
 
@@ -30,9 +31,19 @@ __host__ __device__ constexpr int block_units(int nu, int b) { return nu - 16 * 
 __host__ __device__ constexpr int block_ksteps(int nu, int b) { return (block_units(nu, b) + 3) / 4; }
 __host__ __device__ constexpr int tile_ksteps(int nu) { return block_ksteps(nu, 0) + block_ksteps(nu, 1); }
 __host__ __device__ constexpr int groups(int ks) { return (ks + 3) / 4; }
-// A table of one product: [group of 4 k-steps][out block][64 lanes][4 k-steps] floats
-__host__ __device__ constexpr int table_floats(int ks, int nout) { return groups(ks) * nout * 256; }
+// A table of one product: [group of 4 k-steps][out block][64 lanes][4 k-steps] floats; a last group of one or two
+// k-steps is stored at that width ([out block][64 lanes][1 or 2]), a last group of three at four.
+__host__ __device__ constexpr int last_width(int ks) { return ks % 4 == 1 ? 1 : (ks % 4 == 2 ? 2 : 4); }
+__host__ __device__ constexpr int table_floats(int ks, int nout) {
+    return (groups(ks) - 1) * nout * 256 + nout * 64 * last_width(ks);
+}
+// float offset of the entry of (group g, out block o, lane) and its width
+__host__ __device__ constexpr int entry_offset(int ks, int nout, int g, int o, int lane) {
+    return g < groups(ks) - 1 ? ((g * nout + o) * 64 + lane) * 4
+                              : (groups(ks) - 1) * nout * 256 + (o * 64 + lane) * last_width(ks);
+}
 constexpr int kBiasTile = 32;              // [2 blocks][4 q][4 i]
+constexpr int kSplitBlock = 3 * 64 * 4;    // dwords of one out block of a float16 split table: 3 terms x 64 lanes x 16 bytes
 
 template <bool LARGE>
 struct Dims {
@@ -56,10 +67,11 @@ struct Dims {
 struct NnLayout {
     int conv[4];         // three tap tables of conv layer l, conv_tap[l] floats each, out blocks = (value blocks, gate blocks)
     int conv_tap[4];
-    int gru_ih[2];       // out blocks = (r blocks, z blocks, n blocks)
-    int gru_hh[2];
+    int gru_ih[2];       // out blocks = (r blocks, z blocks, n blocks); layers above the first: float16 split, as gru_hh
+    int gru_hh[2];       // recurrent weights as float16 split A operands: [out block][hi, mid, lo][64 lanes] x 8 float16
     int conv_bias[4];    // [value, gate] bias tiles
     int gru_bias[2];     // [r, z, n-input, n-hidden] bias tiles
+    int gru_scale[2];    // 2^-(14 + Sw), 2^Sw of the layer's recurrent table, then the same of its split input table
     int lds;
     int emb[3];          // embed stage s: one table per input tile (stage 0: one per GRU layer), emb_tab[s] floats each
     int emb_tab[3];
@@ -80,9 +92,9 @@ __host__ __device__ constexpr NnLayout nn_layout() {
     constexpr int gout = 3 * n_blocks(D::hidden);
     for (int g = 0; g < D::layers; ++g) {
         L.gru_ih[g] = at;
-        at += table_floats(tile_ksteps(D::gru_in(g)), gout);
+        at += g == 0 ? table_floats(tile_ksteps(D::gru_in(0)), gout) : gout * kSplitBlock;
         L.gru_hh[g] = at;
-        at += table_floats(tile_ksteps(D::hidden), gout);
+        at += gout * kSplitBlock;
     }
     for (int l = 0; l < D::nc; ++l) {
         L.conv_bias[l] = at;
@@ -91,6 +103,10 @@ __host__ __device__ constexpr NnLayout nn_layout() {
     for (int g = 0; g < D::layers; ++g) {
         L.gru_bias[g] = at;
         at += 4 * kBiasTile;
+    }
+    for (int g = 0; g < D::layers; ++g) {
+        L.gru_scale[g] = at;
+        at += 4;
     }
     L.lds = at;
     for (int s = 0; s <= D::ne; ++s) {
@@ -131,12 +147,23 @@ struct SkipThird {      // r, z, then the n gate's hidden part: output blocks 2 
 };
 
 template <int NOUT, int KS, typename AT = Straight, int NACC>
-__device__ __forceinline__ void mm(f32x4 (&acc)[NACC], const f32x4* a, const float (&bv)[KS]) {
+__device__ __forceinline__ void mm(f32x4 (&acc)[NACC], const float* tab, int lane, const float (&bv)[KS]) {
+    constexpr int G = groups(KS), LW = last_width(KS);
 #pragma unroll
-    for (int g = 0; g < groups(KS); ++g) {
+    for (int g = 0; g < G; ++g) {
         f32x4 av[NOUT];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) av[o] = a[(g * NOUT + o) * 64];
+        for (int o = 0; o < NOUT; ++o) {
+            const float* e = tab + entry_offset(KS, NOUT, g, o, 0);
+            if (g < G - 1 || LW == 4) {
+                av[o] = *reinterpret_cast<const f32x4*>(e + 4 * lane);
+            } else if (LW == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(e + 2 * lane);
+                av[o] = f32x4{t.x, t.y, 0.0f, 0.0f};
+            } else {
+                av[o] = f32x4{e[lane], 0.0f, 0.0f, 0.0f};
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (4 * g + j < KS) {
@@ -165,10 +192,11 @@ __device__ __forceinline__ Tile conv_layer(const f32x4* a_lane, const float* w, 
     for (int vg = 0; vg < 2; ++vg)
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) acc[vg * NB + blk] = bias_block(w + LY.conv_bias[L] + vg * kBiasTile, blk, q);
-    const f32x4* a = a_lane + LY.conv[L] / 4;
-    if (has_m1) mm<NOUT, KS>(acc, a, bm1);
-    mm<NOUT, KS>(acc, a + LY.conv_tap[L] / 4, b0);
-    if (has_p1) mm<NOUT, KS>(acc, a + 2 * (LY.conv_tap[L] / 4), bp1);
+    const int lane = (int)(a_lane - reinterpret_cast<const f32x4*>(w));
+    const float* a = w + LY.conv[L];
+    if (has_m1) mm<NOUT, KS>(acc, a, lane, bm1);
+    mm<NOUT, KS>(acc, a + LY.conv_tap[L], lane, b0);
+    if (has_p1) mm<NOUT, KS>(acc, a + 2 * LY.conv_tap[L], lane, bp1);
     Tile out;
     out.b[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -196,24 +224,69 @@ __device__ __forceinline__ void conv_stage(Tile (&ring)[3], Tile& cur, int p, co
     }
 }
 
-// One GRU cell step of one layer (torch.nn.GRU, gate order r, z, n): h <- (1 - z) n + z h.
+// ---- products on the 16-bit matrix pipe ----------------------------------------------------------------
+// A float32 product as six float16 partial products (rnn_device.h): a hidden state, times 2^14, and a weight table,
+// times 2^Sw, are each the exact sum of three float16 terms; the products left out are below 2^-35 of a product and
+// the accumulation is float32.  A lane's eight values of a tile are exactly its k-slots 8 q + j of
+// v_mfma_f32_16x16x32_f16 (register [j >> 2][j & 3]), so a whole K = 32 is one instruction of 16 cycles where the
+// float32 MFMA takes eight of 32 -- and this pipe runs beside the vector ALU.  Used where the B operand is a hidden
+// state (|h| < 1): the GRU's recurrent products and the input products of the layers above the first.
+struct SplitTile {
+    rnn::u32x4 hi, mid, lo;          // dword jp = k-slots 2 jp (low half) and 2 jp + 1
+};
+
+__device__ __forceinline__ SplitTile split_state(const Tile& h) {
+    SplitTile s;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        const int j = 2 * jp;
+        const rnn::SplitTerms t = rnn::split_pair<true, true>(h.b[j >> 2][j & 3] * rnn::kStateScale,
+                                                              h.b[j >> 2][(j & 3) + 1] * rnn::kStateScale);
+        s.hi[jp] = t.hi;
+        s.mid[jp] = t.mid;
+        s.lo[jp] = t.lo;
+    }
+    return s;
+}
+
+// acc[AT(o)] += unscale * (split table(out block o) . b); `tab`: [out block][hi, mid, lo][64 lanes] x 16 bytes
+template <int NOUT, typename AT = Straight, int NACC>
+__device__ __forceinline__ void mm_split(f32x4 (&acc)[NACC], const float* tab, int lane, const SplitTile& b, float unscale) {
+    const rnn::u32x4* a16 = reinterpret_cast<const rnn::u32x4*>(tab) + lane;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const rnn::u32x4 ah = a16[(o * 3 + 0) * 64], am = a16[(o * 3 + 1) * 64], al = a16[(o * 3 + 2) * 64];
+        f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+        c = MFMA_F16(ah, b.lo, c);                            // smallest terms first
+        c = MFMA_F16(al, b.hi, c);
+        c = MFMA_F16(am, b.mid, c);
+        c = MFMA_F16(ah, b.mid, c);
+        c = MFMA_F16(am, b.hi, c);
+        c = MFMA_F16(ah, b.hi, c);
+        f32x4& dst = acc[AT::at(o)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = fmaf(c[i], unscale, dst[i]);
+    }
+}
+
+// One GRU cell step of one layer (torch.nn.GRU, gate order r, z, n): h <- (1 - z) n + z h.  `hs` is the split of h
+// (of the previous state on entry, of the new one on return).  The first layer's input is the trunk's output `xin`
+// (float32 MFMA); a layer above takes the split `xs` of the new state of the layer below.
 template <bool LARGE, int LAYER>
-__device__ __forceinline__ void gru_step(Tile& h, const float (&xin)[tile_ksteps(Dims<LARGE>::gru_in(LAYER))],
-                                         const f32x4* a_lane, const float* w, bool first, int q) {
+__device__ __forceinline__ void gru_step(Tile& h, SplitTile& hs, const float (&xin)[tile_ksteps(Dims<LARGE>::gru_in(0))],
+                                         const SplitTile& xs, const f32x4* a_lane, const float* w, bool first, int q) {
     using D = Dims<LARGE>;
     constexpr NnLayout LY = nn_layout<LARGE>();
-    constexpr int NB = n_blocks(D::hidden), KSI = tile_ksteps(D::gru_in(LAYER)), KSH = tile_ksteps(D::hidden);
+    constexpr int NB = n_blocks(D::hidden);
     f32x4 acc[4 * NB];                                        // r, z, n-input, n-hidden
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk) acc[a * NB + blk] = bias_block(w + LY.gru_bias[LAYER] + a * kBiasTile, blk, q);
-    mm<3 * NB, KSI>(acc, a_lane + LY.gru_ih[LAYER] / 4, xin);
-    if (!first) {                                             // h_0 = 0
-        float hv[KSH];
-        tile_kvals<D::hidden>(h, hv);
-        mm<3 * NB, KSH, SkipThird<NB>>(acc, a_lane + LY.gru_hh[LAYER] / 4, hv);
-    }
+    const int lane = (int)(a_lane - reinterpret_cast<const f32x4*>(w));
+    if constexpr (LAYER == 0) mm<3 * NB, tile_ksteps(D::gru_in(0))>(acc, w + LY.gru_ih[0], lane, xin);
+    else mm_split<3 * NB>(acc, w + LY.gru_ih[LAYER], lane, xs, w[LY.gru_scale[LAYER] + 2]);
+    if (!first) mm_split<3 * NB, SkipThird<NB>>(acc, w + LY.gru_hh[LAYER], lane, hs, w[LY.gru_scale[LAYER]]);    // h_0 = 0
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
@@ -223,6 +296,21 @@ __device__ __forceinline__ void gru_step(Tile& h, const float (&xin)[tile_ksteps
             const float n = tanh_pre(fmaf(r, acc[3 * NB + blk][i], acc[2 * NB + blk][i]));
             h.b[blk][i] = fmaf(z, h.b[blk][i] - n, n);
         }
+    hs = split_state(h);
+}
+
+// All GRU layers for one position: `x` is the trunk's output there.
+template <bool LARGE>
+__device__ __forceinline__ void gru_layers(Tile (&h)[Dims<LARGE>::layers], SplitTile (&hs)[Dims<LARGE>::layers], const Tile& x,
+                                           const f32x4* a_lane, const float* w, bool first, int q) {
+    using D = Dims<LARGE>;
+    float xin[tile_ksteps(D::gru_in(0))];
+    tile_kvals<D::gru_in(0)>(x, xin);
+    gru_step<LARGE, 0>(h[0], hs[0], xin, hs[0], a_lane, w, first, q);
+    if constexpr (D::layers > 1) {
+        NN_STAGE_FENCE;
+        gru_step<LARGE, 1>(h[1], hs[1], xin, hs[0], a_lane, w, first, q);
+    }
 }
 
 // embed (core/models.py:109-128, eval mode) on the final hidden states, softmax (core/models.py:330), decision.
@@ -234,7 +322,6 @@ __device__ __forceinline__ void embed_head(const Tile (&h)[Dims<LARGE>::layers],
     using D = Dims<LARGE>;
     constexpr NnLayout LY = nn_layout<LARGE>();
     const int q = lane >> 4, n = lane & 15;
-    const f32x4* a_lane = reinterpret_cast<const f32x4*>(blob) + lane;
     Tile e;
     {   // stage 0: columns l * H + u of the head input are unit u of GRU layer l's final state
         constexpr int NB = n_blocks(D::embed_out(0)), KS = tile_ksteps(D::hidden);
@@ -245,7 +332,7 @@ __device__ __forceinline__ void embed_head(const Tile (&h)[Dims<LARGE>::layers],
         for (int l = 0; l < D::layers; ++l) {
             float hv[KS];
             tile_kvals<D::hidden>(h[l], hv);
-            mm<NB, KS>(acc, a_lane + (LY.emb[0] + l * LY.emb_tab[0]) / 4, hv);
+            mm<NB, KS>(acc, blob + LY.emb[0] + l * LY.emb_tab[0], lane, hv);
         }
         e.b[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -260,7 +347,7 @@ __device__ __forceinline__ void embed_head(const Tile (&h)[Dims<LARGE>::layers],
         for (int blk = 0; blk < NB; ++blk) acc[blk] = bias_block(blob + LY.emb_bias[1], blk, q);
         float ev[KS];
         tile_kvals<D::embed_in(1)>(e, ev);
-        mm<NB, KS>(acc, a_lane + LY.emb[1] / 4, ev);
+        mm<NB, KS>(acc, blob + LY.emb[1], lane, ev);
         e.b[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int blk = 0; blk < NB; ++blk)
@@ -272,7 +359,7 @@ __device__ __forceinline__ void embed_head(const Tile (&h)[Dims<LARGE>::layers],
     acc[0] = bias_block(blob + LY.emb_bias[D::ne], 0, q);
     float ev[KS];
     tile_kvals<D::embed_in(D::ne)>(e, ev);
-    mm<1, KS>(acc, a_lane + LY.emb[D::ne] / 4, ev);
+    mm<1, KS>(acc, blob + LY.emb[D::ne], lane, ev);
     // logit 0 is unit 0 = register 0 of lane group 0, logit 1 is unit 1 = register 0 of lane group 1
     const float l0 = __shfl(acc[0][0], n, 64), l1 = __shfl(acc[0][0], 16 + n, 64);
     const float m = fmaxf(l0, l1);

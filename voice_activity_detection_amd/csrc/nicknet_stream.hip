@@ -202,8 +202,11 @@ __global__ __launch_bounds__(kWaves * 64) void nicknet_stream_kernel(const float
 
         // ---- the GRU over the 30 positions ----
         Tile h[D::layers];
+        SplitTile hs[D::layers];                                 // written by every step before it is read
 #pragma unroll
         for (int l = 0; l < D::layers; ++l) h[l].b[0] = h[l].b[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int l = 0; l < D::layers; ++l) hs[l].hi = hs[l].mid = hs[l].lo = rnn::u32x4{0u, 0u, 0u, 0u};
 #pragma unroll 1
         for (int p = 0; p < kT; ++p) {
             // R has been rotated p times: lane n holds column (n + p) % 16 of each tile; R[0] and R[1] are the two
@@ -226,17 +229,7 @@ __global__ __launch_bounds__(kWaves * 64) void nicknet_stream_kernel(const float
                 R[1] = R[2];
             }
             NN_STAGE_FENCE;
-            {
-                float xin[tile_ksteps(C)];
-                tile_kvals<C>(x, xin);
-                gru_step<LARGE, 0>(h[0], xin, a_lane, lds, p == 0, q);
-            }
-            NN_STAGE_FENCE;
-            if constexpr (D::layers > 1) {
-                float xin[tile_ksteps(H)];
-                tile_kvals<H>(h[0], xin);
-                gru_step<LARGE, D::layers - 1>(h[D::layers - 1], xin, a_lane, lds, p == 0, q);
-            }
+            gru_layers<LARGE>(h, hs, x, a_lane, lds, p == 0, q);
         }
         embed_head<LARGE>(h, blob, lane, w, n_windows, p_out, dec_out, mode, threshold, nullptr);
     }

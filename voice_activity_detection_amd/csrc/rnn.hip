@@ -1289,28 +1289,6 @@ int rnn_forward(bool lstm, const float* x, int64_t n_windows, WindowMap wm, cons
 
 namespace vad {
 namespace {
-// Host twin of split_pair: x -> the three 16-bit terms (hi, mid, lo), bfloat16 by truncation or float16 by
-// round-to-nearest; *finite is cleared when a float16 term overflows.
-inline void split3_host(float x, bool f16, uint16_t out[3], bool* finite) {
-    float r = x;
-    for (int term = 0; term < 3; ++term) {
-        if (f16) {
-            const _Float16 h = (_Float16)r;
-            memcpy(&out[term], &h, 2);
-            const float back = (float)h;
-            if (!(back - back == 0.0f)) *finite = false;
-            r -= back;
-        } else {
-            uint32_t bits;
-            memcpy(&bits, &r, 4);
-            const uint32_t hb = bits & 0xFFFF0000u;
-            float hi;
-            memcpy(&hi, &hb, 4);
-            out[term] = (uint16_t)(hb >> 16);
-            r -= hi;
-        }
-    }
-}
 }  // namespace
 }  // namespace vad
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "vad_internal.h"
 
@@ -222,6 +223,29 @@ __device__ __forceinline__ SplitTerms split_pair(float x0, float x1) {
         }
     }
     return SplitTerms{hi, mid, lo};
+}
+
+// Host twin of split_pair: x -> the three 16-bit terms (hi, mid, lo), bfloat16 by truncation or float16 by
+// round-to-nearest; *finite is cleared when a float16 term overflows.
+inline void split3_host(float x, bool f16, uint16_t out[3], bool* finite) {
+    float r = x;
+    for (int term = 0; term < 3; ++term) {
+        if (f16) {
+            const _Float16 h = (_Float16)r;
+            memcpy(&out[term], &h, 2);
+            const float back = (float)h;
+            if (!(back - back == 0.0f)) *finite = false;
+            r -= back;
+        } else {
+            uint32_t bits;
+            memcpy(&bits, &r, 4);
+            const uint32_t hb = bits & 0xFFFF0000u;
+            float hi;
+            memcpy(&hi, &hb, 4);
+            out[term] = (uint16_t)(hb >> 16);
+            r -= hi;
+        }
+    }
 }
 
 __host__ __device__ inline int split_index(int mi, int ni, int i) { return (2 * mi + ni) * 4 + i; }
