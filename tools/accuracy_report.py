@@ -74,3 +74,21 @@ for name, scale, hidden in (('gru_h90', 1.0, 90), ('gru_large x0.05', 0.05, 30),
         e = np.abs(p.cpu().numpy() - y64)
         row.append('%s max %.2e mean %.2e' % (mode, e.max(), e.mean()))
     print('%-16s ' % name + ' | '.join(row))
+
+# NickNet: float32 MFMA for the convolutions and the first GRU layer's input, six float16 partial products for the
+# products of a hidden state; the dense-batch kernel and the stride-1 kernel (trunk once per row) against float64
+print('\nNickNet against a float64 evaluation of the same weights (20000 windows):')
+from oracle import nicknet_ref
+for large in (True, False):
+    r = nicknet_ref.make_nicknet(large)
+    net = pkg.NickNet(large=large)
+    net.load_state_dict(r.state_dict())
+    with torch.no_grad():
+        y32 = r(torch.from_numpy(xw[:20000])).numpy()
+        y64 = r.double()(x64).numpy()
+    r.float()
+    p_stream, _ = net.score(fdev, window_stride=24)
+    p_batch, _ = net.score(torch.from_numpy(xw[:20000]).cuda())
+    e = np.abs(p_stream.cpu().numpy() - y64)
+    print('nicknet_%-6s torch-cpu-f32 %.2e | stride-1 kernel max %.2e mean %.2e | dense-batch kernel equal bits: %s'
+          % ('large' if large else 'small', np.abs(y32 - y64).max(), e.max(), e.mean(), bool(torch.equal(p_stream, p_batch))))
