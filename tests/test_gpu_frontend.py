@@ -208,6 +208,54 @@ def test_full_size_stream_properties(vad):
     assert float((p32 - p).abs().max()) <= 1e-5                     # all 12 M windows, the two matrix modes
 
 
+@pytest.mark.parametrize('kind', ['nicknet', 'nicknet_small', 'densenet', 'densenet_large', 'lstm_small', 'gru_h90'])
+def test_full_size_window_independence_of_the_other_models(vad, kind):
+    """The other stride-1 model kernels at the benchmark's size (100 h = 12 M feature rows): every window's posterior
+    is a function of its own 30 rows, so windows sampled across the stream and recomputed from a materialised
+    (B,30,24) batch -- which takes the any-placement kernel -- reproduce the stream's values: bit for bit where the two
+    kernels run the same instruction chains (NickNet, DenseNet), within the 1e-5 bar where the stream kernel forms its
+    products on the 16-bit pipe (LSTM, wide GRU).  Also determinism and well-formed outputs."""
+    from oracle import models_ref, nicknet_ref
+    n = 12_000_000
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * 2 ** 30:
+        pytest.skip('needs 24 GB of free device memory (an idle MI355X has 288 GB)')
+    if kind.startswith('nicknet'):
+        ref = nicknet_ref.make_nicknet(kind == 'nicknet')
+        net = vad.NickNet(large=kind == 'nicknet')
+    elif kind.startswith('densenet'):
+        ref = models_ref.make_model(kind)
+        net = vad.DenseNet(large=kind.endswith('large'))
+    elif kind == 'gru_h90':
+        ref = models_ref.make_model('gru_large', hidden=90)
+        net = vad.Net(large=True, lstm=False, hidden=90)
+    else:
+        ref = models_ref.make_model(kind)
+        net = vad.Net(large=False, lstm=True)
+    net.load_state_dict(ref.state_dict())
+    g = torch.Generator(device='cuda').manual_seed(11)
+    feat = torch.empty((n, 24), device='cuda')
+    feat.normal_(0.0, 6.0, generator=g)
+    p, dec = net.score(feat, window_stride=24)
+    torch.cuda.synchronize()
+    assert p.shape == (n - 29, 2) and bool(torch.isfinite(p).all())
+    assert float((p.sum(1) - 1).abs().max()) < 1e-6
+    assert bool(((p[:, 1] > p[:, 0]).to(torch.uint8) == dec).all())
+    p2, _ = net.score(feat, window_stride=24)
+    assert torch.equal(p, p2)
+    idx = torch.cat((torch.tensor([0, 1, 15, 16, 17, 127, 128, n - 31, n - 30], device='cuda'),
+                     torch.randint(0, n - 29, (2000,), generator=g, device='cuda')))
+    rows = idx[:, None] + torch.arange(30, device='cuda')[None, :]
+    pb, _ = net.score(feat[rows].contiguous())
+    if kind.startswith(('nicknet', 'densenet')):
+        assert torch.equal(pb, p[idx])
+    else:
+        assert float((pb - p[idx]).abs().max()) <= 1e-5
+    with torch.no_grad():
+        y = ref(feat[rows[:64]].cpu()).numpy()
+    assert np.abs(p[idx[:64]].cpu().numpy() - y).max() <= 1e-5
+
+
 def test_gain_and_shift_properties(vad):
     """Size-independent properties on a long stream: c1..c12 ignore a gain of 2 (the DCT rows annihilate the
     log 4 offset), and with the whole stream as one slice the features of a stream that starts one frame
