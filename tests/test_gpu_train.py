@@ -89,3 +89,25 @@ def test_netvad_decisions_per_frame(vad, kind, init_pos, length, capsys):
     np.testing.assert_array_equal(out[clear], r_out[clear])
     assert clear.mean() > 0.99
     assert vad.train.netvad(net, data, noise_level='0') is None
+
+
+@pytest.mark.parametrize('model', ['gru_large', 'densenet', 'nicknet'])
+def test_end_to_end_example_runs(vad, model, capsys):
+    """examples/evaluate_synthetic.py: synthetic audio -> process_training_data -> far / roc_auc / netvad, every
+    stage on the device kernels; outputs are well formed (the stages themselves are checked against the oracle above
+    and in the front-end / overlay / model tests)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'evaluate_synthetic.py')
+    spec = importlib.util.spec_from_file_location('evaluate_synthetic', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    results, curves, (raw, lab, decisions) = mod.main(model, 70000)
+    assert set(results) == {'None', '-15', '-3'}
+    for far, frr in results.values():
+        assert 0.0 <= far <= 100.0 and 0.0 <= frr <= 100.0
+    fpr, tpr, thr, area = curves[model]
+    assert fpr[0] == 0.0 and tpr[-1] == 1.0 and 0.0 <= area <= 1.0
+    assert raw.shape == (670, 480) and lab.shape == decisions.shape == (670,)
+    assert set(np.unique(decisions)) <= {0.0, 1.0}
+    assert 'FAR: ' in capsys.readouterr().out
